@@ -1,0 +1,171 @@
+/*
+ * mmgp.h -- C-ABI of libmmgp.so: the MI355X (gfx950) implementation of the
+ * multigrid V-cycle hot path of michaelxu3/MeshlessMultigridPoisson.
+ *
+ * The reference has no FFI; its boundary for this path is the public surface of
+ * `Grid` (MeshlessPoisson/grid.h:20-79) and `Multigrid`
+ * (MeshlessPoisson/multigrid.h:4-23).  Each entry point below names the
+ * reference member it replaces.  The host-side C++ classes that mirror
+ * Grid/Multigrid (meshlessmultigridpoisson_amd/csrc/host) call ONLY these
+ * functions for device work; INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers + sizes, int status (0 = MMG_OK),
+ *     nothing throws across the boundary; mmg_last_error() gives the message
+ *     of the last failure on the calling thread.
+ *   - all host arrays are borrowed for the duration of the call only;
+ *     device buffers are owned by the handles.
+ *   - fp64 values, 32-bit int indices (Eigen's defaults in the reference).
+ *   - all device work of a handle is issued on one HIP stream (mmg_set_stream);
+ *     calls that return scalars or copy to host synchronise that stream.
+ *   - there is NO CPU fallback: every call fails with MMG_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef MMGP_H
+#define MMGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    MMG_OK = 0,
+    MMG_ERR_INVALID = 1,    /* bad argument / inconsistent sizes               */
+    MMG_ERR_NO_DEVICE = 2,  /* no usable HIP device                            */
+    MMG_ERR_HIP = 3,        /* a HIP runtime call failed                       */
+    MMG_ERR_UNSUPPORTED = 4,/* matrix structure outside what the path handles  */
+    MMG_ERR_COMM = 5        /* RCCL failure                                    */
+};
+
+typedef struct mmg_level mmg_level;         /* one reference Grid on device    */
+typedef struct mmg_transfer mmg_transfer;   /* one restriction/prolongation    */
+typedef struct mmg_hierarchy mmg_hierarchy; /* one reference Multigrid         */
+typedef struct mmg_spmv mmg_spmv;           /* generic CSR operator (D_x, ...) */
+
+/* What mmg_level_create needs == the state Grid::sor / residual /
+ * bound_eval_neumann / boundaryOp read (grid.h:23-38). */
+typedef struct {
+    int n;                 /* laplaceMatSize_ (points)                          */
+    int a_size;            /* laplaceMat_->rows(): n, or n+1 with neumann_flag  */
+    const int *rowptr;     /* laplaceMat_->outerIndexPtr()  [a_size+1]          */
+    const int *col;        /* laplaceMat_->innerIndexPtr()  [nnz]               */
+    const double *val;     /* laplaceMat_->valuePtr()       [nnz]               */
+    const int *bcflags;    /* bcFlags_ [n]: 0 interior, 1 dirichlet, 2 neumann  */
+    int neumann_flag;      /* neumannFlag_                                      */
+    double omega;          /* properties_.omega                                 */
+    int iters;             /* properties_.iters                                 */
+    int nb;                /* boundaries_.size()                                */
+    const int *btype;      /* boundaries_[b].type            [nb]               */
+    const int *bptr;       /* offsets into bpts/bvals        [nb+1]             */
+    const int *bpts;       /* boundaries_[b].bcPoints, concatenated             */
+    const double *bvals;   /* boundaries_[b].values,   concatenated             */
+    /* optional layout hints (0 / NULL = choose automatically) */
+    const int *tile_ptr;   /* [n_tiles+1] contiguous point ranges, one per tile */
+    int n_tiles;
+    int tile_size;         /* points per tile when tile_ptr is NULL             */
+    int lanes_per_row;     /* 1,2,4,8,16,32,64                                  */
+} mmg_level_desc;
+
+/* Introspection of the packed device layout (for DESIGN/bench reporting). */
+typedef struct {
+    int n_tiles;
+    int n_phases;            /* dependent launches per relaxation sweep         */
+    int n_groups;            /* row groups over all tiles                       */
+    int lanes_per_row;
+    int max_lds_bytes;       /* LDS per workgroup                               */
+    long long sor_rows;      /* interior rows relaxed per sweep                 */
+    long long sor_nnz;       /* stored off-diagonal entries of those rows       */
+    long long stream_bytes;  /* packed bytes read per sweep (matrix stream)     */
+    long long halo_entries;  /* ghost-of-tile values staged per sweep           */
+    long long neumann_rows;
+} mmg_level_info;
+
+const char *mmg_last_error(void);
+int mmg_device_count(int *count);
+int mmg_set_device(int device);
+/* HIP stream (hipStream_t as void*) used for all subsequent launches of this
+ * thread's handles; NULL selects the library's own non-blocking stream. */
+int mmg_set_stream(void *hip_stream);
+int mmg_synchronize(void);
+
+/* ---- level == Grid ------------------------------------------------------- */
+int mmg_level_create(mmg_level **out, const mmg_level_desc *desc);
+void mmg_level_destroy(mmg_level *lv);
+int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info);
+/* values_ / source_ mirrors (grid.h:23,25); count must be a_size */
+int mmg_level_set_x(mmg_level *lv, const double *x, int count);
+int mmg_level_get_x(mmg_level *lv, double *x, int count);
+int mmg_level_set_rhs(mmg_level *lv, const double *b, int count);
+int mmg_level_get_rhs(mmg_level *lv, double *b, int count);
+/* boundaries_[b].values for all boundaries, concatenated like desc.bvals */
+int mmg_level_set_bvals(mmg_level *lv, const double *bvals, int count);
+int mmg_level_set_omega_iters(mmg_level *lv, double omega, int iters);
+/* Grid::sor(laplaceMat_, values_, &source_)  grid.cpp:104-146 */
+int mmg_level_sor(mmg_level *lv);
+/* nsweeps passes of the row loop + bound_eval_neumann (one `it` each) */
+int mmg_level_sweeps(mmg_level *lv, int nsweeps);
+/* Grid::bound_eval_neumann  grid.cpp:73-103 */
+int mmg_level_bound_eval_neumann(mmg_level *lv);
+/* Grid::residual  grid.cpp:147-151 ; r_out (host, a_size) may be NULL to keep
+ * the result on the device only */
+int mmg_level_residual(mmg_level *lv, double *r_out, int count);
+/* ||residual()||_1 / ||source_||_1   (multigrid.cpp:112-115, testing_functions.cpp:438) */
+int mmg_level_residual_ratio(mmg_level *lv, double *ratio);
+/* Grid::boundaryOp("coarse"|"fine")  grid.cpp:42-51 */
+int mmg_level_boundary_op(mmg_level *lv, int coarse);
+/* Grid::modify_coeff_neumann("coarse"|"fine")  grid.cpp:62-72 */
+int mmg_level_modify_coeff_neumann(mmg_level *lv, int coarse);
+/* values_->setZero()  multigrid.cpp:76,93 */
+int mmg_level_zero_x(mmg_level *lv);
+/* hipEvent-timed relaxation sweeps on the handle's stream: `reps` timed calls of
+ * `nsweeps` sweeps; ms_out[reps] receives each call's device time.  If
+ * phase_ms_sum is non-NULL it receives the summed duration of the sweep-phase
+ * kernels only (measured with per-launch events in a second pass). */
+int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out);
+int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out);
+
+/* ---- transfers == restrictionMatrices_/prolongMatrices_ ------------------- */
+/* The reference stores them column-major (multigrid.h:8-9): pass
+ * outer=colptr[cols+1], inner=row indices with col_major=1; a row-major CSR
+ * (outer=rowptr[rows+1], inner=column indices) is accepted with col_major=0. */
+int mmg_transfer_create(mmg_transfer **out, int rows, int cols, const int *outer,
+                        const int *inner, const double *val, int col_major);
+void mmg_transfer_destroy(mmg_transfer *t);
+/* multigrid.cpp:81-86: coarse.source_[0:n_c) = R * fine.residual()[0:n_f);
+ * fix_vector_bound_coarse; if fine.neumannFlag_: source_[last]=0 and
+ * modify_coeff_neumann("coarse"). */
+int mmg_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R);
+/* multigrid.cpp:102-106: fine.values_[0:n_f) += mask(P * coarse.values_[0:n_c)) */
+int mmg_prolong_add(mmg_level *coarse, mmg_level *fine, mmg_transfer *P);
+
+/* ---- hierarchy == Multigrid ----------------------------------------------- */
+/* levels sorted coarse -> fine like grids_ (multigrid.cpp:116-122); R[i] maps
+ * level i -> i-1 (R[0] NULL), P[i] maps level i -> i+1 (P[n-1] NULL).  Handles
+ * are borrowed, not owned.  frac_step selects FracStepMultigrid.cpp:60-112. */
+int mmg_hierarchy_create(mmg_hierarchy **out, mmg_level **levels, int nlevels,
+                         mmg_transfer **R, mmg_transfer **P, int frac_step);
+void mmg_hierarchy_destroy(mmg_hierarchy *h);
+/* Multigrid::vCycle  multigrid.cpp:62-110 ; *resid_before = residuals_.back()
+ * (-1 for the frac-step single-grid early-out, which pushes nothing) */
+int mmg_vcycle(mmg_hierarchy *h, double *resid_before);
+/* Multigrid::residual  multigrid.cpp:112-115 */
+int mmg_hierarchy_residual(mmg_hierarchy *h, double *ratio);
+/* ncycles V-cycles back to back, residual history written to resid[ncycles];
+ * total device time (hipEvents) to *ms if non-NULL */
+int mmg_vcycles(mmg_hierarchy *h, int ncycles, double *resid, float *ms);
+
+/* ---- generic CSR operator (fractionalStepGrid.cpp:101-151: D_x, D_y, lap) -- */
+int mmg_spmv_create(mmg_spmv **out, int rows, int cols, const int *rowptr,
+                    const int *col, const double *val);
+void mmg_spmv_destroy(mmg_spmv *m);
+/* y = A x on host vectors (uploads x, downloads y) */
+int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMGP_H */

@@ -1,0 +1,114 @@
+// plan.hpp -- packed "tile plan": the HBM layout every gfx950 kernel of this
+// library streams.  Built on the host (plan.cpp), consumed by kernels.hip.
+//
+// A plan turns "for each row r of a CSR matrix, in a given sequential order,
+// combine sum_j a_rj * in[j] into out[r]" into
+//
+//   phases  : sets of tiles with no mutual coupling  -> one kernel launch each
+//   tiles   : a contiguous chunk of the row sequence  -> one wavefront each;
+//             every input value the tile touches is staged ONCE in LDS
+//             (own range: coalesced; the rest: gathered through `halo`)
+//   groups  : 64/L rows relaxed together by one wavefront, L lanes per row;
+//             groups of a tile are ordered by dependency level, so executing
+//             them in order inside one wavefront reproduces the sequential
+//             (Gauss-Seidel) order of the reference exactly
+//
+// Per group the stream holds, 16-byte aligned and in this order:
+//   RowMeta  meta[G]            (8 B each)
+//   double   diag[G]
+//   double   val [plen*64]      val [q*64 + lane] : entry q of lane's row share
+//   uint16   slot[plen4*64*4]   slot[((q/4)*64 + lane)*4 + q%4] : LDS slot of the
+//                               column (tile-local, 16 bit -- 10 B per stored
+//                               entry instead of CSR's 12 B)
+// with G = 64/L, lane = row_in_group*L + sub, plen4 = ceil(plen/4).
+// Padding entries carry val = 0 and point at the tile's zero slot.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mmg {
+
+struct CsrView {
+    int rows = 0, cols = 0;
+    const int *rowptr = nullptr;
+    const int *col = nullptr;
+    const double *val = nullptr;
+};
+
+struct TileDesc {          // 48 bytes, read by the kernels with scalar loads
+    uint64_t stream_off;   // bytes into Plan::stream
+    uint64_t halo_off;     // into Plan::halo
+    uint32_t row0;         // own range [row0, row0+n_own) of the input vector
+    uint32_t n_own;
+    uint32_t n_halo;
+    uint32_t n_groups;
+    uint32_t ghead_off;    // into Plan::ghead
+    uint32_t n_rows;       // rows handled by the tile
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(TileDesc) == 48, "TileDesc layout");
+
+struct RowMeta {
+    uint32_t gid;          // output index of the row
+    uint16_t self;         // LDS slot holding in[gid] (0xFFFF: not staged)
+    uint16_t flags;        // bit0: row has the multiplier column (coefficient 1)
+};
+static_assert(sizeof(RowMeta) == 8, "RowMeta layout");
+
+constexpr uint16_t kNoSlot = 0xFFFF;
+constexpr int kMaxSlots = 7936;  // (slots+1)*8 B + group heads must fit 64 KiB LDS
+
+struct Plan {
+    int L = 4;                         // lanes per row
+    int n_tiles = 0;
+    std::vector<TileDesc> tiles;
+    std::vector<int32_t> halo;         // input indices staged after the own range
+    std::vector<uint32_t> ghead;       // per group: n_rows | plen << 8
+    std::vector<uint8_t> stream;       // packed groups
+    std::vector<int32_t> phase_ptr;    // n_phases + 1
+    std::vector<int32_t> phase_tiles;  // tiles ordered by phase
+    int max_slots = 0;                 // max over tiles of n_own + n_halo + 1
+    int max_groups = 0;                // max groups of one tile
+    long long n_rows = 0;              // rows in the plan
+    long long n_nnz = 0;               // stored (non-padding) entries
+    long long n_groups = 0;
+    int n_phases() const { return (int)phase_ptr.size() - 1; }
+    size_t lds_bytes() const { return (size_t)max_slots * 8 + (size_t)max_groups * 4; }
+};
+
+struct PlanSpec {
+    CsrView A;
+    // Rows of A handled by the plan, in the reference's sequential order.
+    // row id == output index == (for in-place plans) input index.
+    const int32_t *rows = nullptr;
+    int64_t n_rows = 0;
+    // Tile boundaries as offsets into rows[] (n_tiles+1 entries).
+    const int64_t *tile_ptr = nullptr;
+    int n_tiles = 0;
+    // Optional per-tile own range of the INPUT vector staged coalesced
+    // (own_lo[t], own_hi[t]); nullptr = everything goes through the halo list.
+    const int32_t *own_lo = nullptr;
+    const int32_t *own_hi = nullptr;
+    bool extract_diag = false;  // pull a_rr out of the sum (SOR / bound_eval / residual)
+    bool need_self = false;     // in[gid] must be staged even if a_rr is absent
+    bool in_place = false;      // out aliases in: honour sequential dependencies
+    int mult_col = -1;          // column of the dense multiplier (stripped; must be 1.0)
+    int L = 4;
+    int n_threads = 0;          // 0 = hardware concurrency
+};
+
+// Returns empty string on success, otherwise the reason (plan left unusable).
+std::string build_plan(const PlanSpec &spec, Plan *out);
+
+// Helpers shared with capi.cpp
+std::vector<int64_t> uniform_tile_ptr(int64_t n_rows, int rows_per_tile);
+
+inline size_t group_bytes(int L, int plen)
+{
+    const int G = 64 / L;
+    const int plen4 = (plen + 3) / 4;
+    return (size_t)16 * G + (size_t)plen * 512 + (size_t)plen4 * 512;
+}
+
+}  // namespace mmg

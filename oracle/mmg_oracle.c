@@ -1,0 +1,219 @@
+/*
+ * mmg_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE).
+ * See mmg_oracle.h for the scope statement and the "PARITY UNPINNED" note.
+ *
+ * Every function names the reference lines it restates
+ * (paths relative to /root/reference/MeshlessPoisson/).
+ * Build with -ffp-contract=off so a*b+c is evaluated as the reference's
+ * (MSVC, no FMA contraction) separate multiply and add.
+ */
+#include "mmg_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* grid.cpp:42-51  Grid::boundaryOp -- Dirichlet points take 0 ("coarse") or
+ * their prescribed boundary value ("fine"). */
+void orc_boundary_op(orc_level *g, int coarse)
+{
+    for (int b = 0; b < g->nb; ++b) {
+        if (g->btype[b] != 1) continue;
+        for (int k = g->bptr[b]; k < g->bptr[b + 1]; ++k)
+            g->x[g->bpts[k]] = coarse ? 0.0 : g->bvals[k];
+    }
+}
+
+/* grid.cpp:62-72  Grid::modify_coeff_neumann -- Neumann points of the RHS take
+ * 0 / their boundary value; the last entry of source_ is zeroed
+ * unconditionally (grid.cpp:71), also on Dirichlet-only grids. */
+void orc_modify_coeff_neumann(orc_level *g, int coarse)
+{
+    for (int b = 0; b < g->nb; ++b) {
+        if (g->btype[b] != 2) continue;
+        for (int k = g->bptr[b]; k < g->bptr[b + 1]; ++k)
+            g->b[g->bpts[k]] = coarse ? 0.0 : g->bvals[k];
+    }
+    g->b[g->a_size - 1] = 0.0;
+}
+
+/* grid.cpp:197-205  Grid::fix_vector_bound_coarse */
+void orc_fix_vector_bound_coarse(const orc_level *g, double *vec)
+{
+    for (int b = 0; b < g->nb; ++b) {
+        if (g->btype[b] != 1) continue;
+        for (int k = g->bptr[b]; k < g->bptr[b + 1]; ++k)
+            vec[g->bpts[k]] = 0.0;
+    }
+}
+
+/* grid.cpp:73-103  Grid::bound_eval_neumann -- point-wise solve of every
+ * Neumann row for its own unknown, boundaries and points in list order. */
+void orc_bound_eval_neumann(orc_level *g)
+{
+    for (int b = 0; b < g->nb; ++b) {
+        if (g->btype[b] != 2) continue;
+        for (int k = g->bptr[b]; k < g->bptr[b + 1]; ++k) {
+            const int c = g->bpts[k];
+            double diag = 0.0;
+            double acc = g->b[c];
+            for (int p = g->rowptr[c]; p < g->rowptr[c + 1]; ++p) {
+                if (g->col[p] == c) { diag = g->val[p]; continue; }
+                acc -= g->x[g->col[p]] * g->val[p];
+            }
+            g->x[c] = acc / diag;
+        }
+    }
+}
+
+/* grid.cpp:112-145: one pass of the row loop of Grid::sor followed by
+ * bound_eval_neumann (grid.cpp:144). Rows with bcFlags != 0 are skipped except
+ * the Neumann multiplier row i == rows-1 (grid.cpp:118). */
+static void sweep_once(orc_level *g)
+{
+    const int rows = g->a_size;
+    for (int i = 0; i < rows; ++i) {
+        if (!(g->neumann_flag && i == rows - 1) && g->bcflags[i] != 0) continue;
+        double xi = 0.0, diag = 0.0;
+        for (int p = g->rowptr[i]; p < g->rowptr[i + 1]; ++p) {
+            const int j = g->col[p];
+            if (j == i) { diag = g->val[p]; continue; }
+            xi -= g->val[p] * g->x[j];
+        }
+        xi += g->b[i];
+        xi *= g->omega / diag;
+        xi += (1 - g->omega) * g->x[i];
+        g->x[i] = xi;
+    }
+    orc_bound_eval_neumann(g);
+}
+
+void orc_sor_sweeps(orc_level *g, int nsweeps)
+{
+    for (int it = 0; it < nsweeps; ++it) sweep_once(g);
+}
+
+/* grid.cpp:104-146  Grid::sor */
+void orc_sor(orc_level *g) { orc_sor_sweeps(g, g->iters); }
+
+/* grid.cpp:147-151  Grid::residual -- r = source_ - laplaceMat_*values_
+ * (Eigen row-major product: per row, accumulate in stored (ascending column)
+ * order, then subtract), then Dirichlet entries zeroed. */
+void orc_residual(const orc_level *g, double *r)
+{
+    for (int i = 0; i < g->a_size; ++i) {
+        double ax = 0.0;
+        for (int p = g->rowptr[i]; p < g->rowptr[i + 1]; ++p)
+            ax += g->val[p] * g->x[g->col[p]];
+        r[i] = g->b[i] - ax;
+    }
+    orc_fix_vector_bound_coarse(g, r);
+}
+
+/* Eigen lpNorm<1>() */
+double orc_l1(const double *v, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += fabs(v[i]);
+    return s;
+}
+
+/* multigrid.cpp:112-115  Multigrid::residual */
+double orc_mg_residual(const orc_level *fine, double *work)
+{
+    orc_residual(fine, work);
+    return orc_l1(work, fine->a_size) / orc_l1(fine->b, fine->a_size);
+}
+
+/* Eigen column-major sparse * dense vector: y = 0; for each column j, for each
+ * stored (i,j): y[i] += val * x[j]  (multigrid.cpp:81,102). */
+void orc_csc_spmv(const orc_csc *m, const double *x, double *y)
+{
+    for (int i = 0; i < m->rows; ++i) y[i] = 0.0;
+    for (int j = 0; j < m->cols; ++j) {
+        const double xj = x[j];
+        for (int p = m->colptr[j]; p < m->colptr[j + 1]; ++p)
+            y[m->rowidx[p]] += m->val[p] * xj;
+    }
+}
+
+/* multigrid.cpp:62-110 Multigrid::vCycle; FracStepMultigrid.cpp:60-112 for
+ * frac_step (single-grid early-out :64-67, otherwise identical arithmetic). */
+double orc_vcycle(orc_level *lv, int nl, const orc_csc *R, const orc_csc *P,
+                  int frac_step)
+{
+    orc_level *fine = &lv[nl - 1];
+    if (frac_step && nl == 1) { orc_sor(fine); return -1.0; }
+
+    int maxsz = 0;
+    for (int i = 0; i < nl; ++i) if (lv[i].a_size > maxsz) maxsz = lv[i].a_size;
+    double *work = (double *)malloc(sizeof(double) * (size_t)maxsz);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)maxsz);
+
+    const double resid = orc_mg_residual(fine, work);      /* :66 */
+    orc_bound_eval_neumann(fine);                           /* :68 */
+
+    orc_level *curr = fine;
+    for (int i = nl - 1; i > 0; --i) {                      /* :71-88 */
+        curr = &lv[i];
+        orc_level *coarse = &lv[i - 1];
+        if (i != nl - 1) memset(curr->x, 0, sizeof(double) * (size_t)curr->a_size);
+        orc_boundary_op(curr, i != nl - 1);
+        orc_sor(curr);
+        orc_residual(curr, work);
+        orc_csc_spmv(&R[i], work, tmp);                     /* first n_f entries of r */
+        memcpy(coarse->b, tmp, sizeof(double) * (size_t)coarse->n);
+        orc_fix_vector_bound_coarse(coarse, coarse->b);
+        if (curr->neumann_flag) {
+            coarse->b[coarse->a_size - 1] = 0.0;
+            orc_modify_coeff_neumann(coarse, 1);
+        }
+    }
+    /* :91 -- boundaryOp("coarse") hits whatever currGrid still points at
+     * (level 1 when nl>1, the finest/only level when nl==1). */
+    orc_boundary_op(curr, 1);
+    curr = &lv[0];
+    memset(curr->x, 0, sizeof(double) * (size_t)curr->a_size);
+    orc_sor(curr);
+    orc_sor(curr);
+
+    for (int i = 1; i < nl; ++i) {                          /* :99-109 */
+        curr = &lv[i];
+        orc_csc_spmv(&P[i - 1], lv[i - 1].x, tmp);
+        if (!curr->neumann_flag) orc_fix_vector_bound_coarse(curr, tmp);
+        for (int k = 0; k < curr->n; ++k) curr->x[k] += tmp[k];
+        orc_sor(curr);
+    }
+    free(work);
+    free(tmp);
+    return resid;
+}
+
+/* Not in the reference: the once-per-sweep ghost refresh schedule of the
+ * multi-GPU fast mode (DESIGN.md "Multi-GPU"). Same arithmetic as sweep_once,
+ * but a column owned by another part is read from the start-of-sweep copy. */
+void orc_sor_hybrid(orc_level *g, const int *part, int nparts, int nsweeps)
+{
+    (void)nparts;
+    const int rows = g->a_size;
+    double *old = (double *)malloc(sizeof(double) * (size_t)rows);
+    for (int it = 0; it < nsweeps; ++it) {
+        memcpy(old, g->x, sizeof(double) * (size_t)rows);
+        for (int i = 0; i < rows; ++i) {
+            const int mult = (g->neumann_flag && i == rows - 1);
+            if (!mult && g->bcflags[i] != 0) continue;
+            double xi = 0.0, diag = 0.0;
+            for (int p = g->rowptr[i]; p < g->rowptr[i + 1]; ++p) {
+                const int j = g->col[p];
+                if (j == i) { diag = g->val[p]; continue; }
+                const int local = mult || j >= g->n || part[j] == part[i];
+                xi -= g->val[p] * (local ? g->x[j] : old[j]);
+            }
+            xi += g->b[i];
+            xi *= g->omega / diag;
+            xi += (1 - g->omega) * g->x[i];
+            g->x[i] = xi;
+        }
+        orc_bound_eval_neumann(g);
+    }
+    free(old);
+}

@@ -1,0 +1,80 @@
+/*
+ * mmg_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of the multigrid V-cycle hot path of
+ * michaelxu3/MeshlessMultigridPoisson (MeshlessPoisson/grid.cpp, multigrid.cpp,
+ * FracStepMultigrid.cpp).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may call into this file, and only as the checker.
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors, fixtures or asserting
+ * tests for this path, and its hot files need Eigen (absent here), so the
+ * reference itself cannot be run.  This restatement follows the reference loops
+ * line by line (citations at each function) and is anchored on the reference's
+ * call sites; see DESIGN.md "Oracle".
+ *
+ * Storage conventions are the reference's: row-major CSR for laplaceMat_
+ * (grid.h:33), column-major CSC for the transfer matrices (multigrid.h:8-9),
+ * fp64 values, 32-bit int indices.
+ */
+#ifndef MMG_ORACLE_H
+#define MMG_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One multigrid level == one reference `Grid` (grid.h:23-38). */
+typedef struct {
+    int n;              /* laplaceMatSize_ : number of points                  */
+    int a_size;         /* rows of laplaceMat_ : n (+1 if neumann_flag)        */
+    const int *rowptr;  /* outerIndexPtr, a_size+1                             */
+    const int *col;     /* innerIndexPtr                                       */
+    const double *val;  /* valuePtr                                            */
+    double *x;          /* values_  (a_size)                                   */
+    double *b;          /* source_  (a_size)                                   */
+    const int *bcflags; /* bcFlags_ (n): 0 interior, 1 dirichlet, 2 neumann    */
+    int neumann_flag;   /* neumannFlag_                                        */
+    double omega;       /* properties_.omega                                   */
+    int iters;          /* properties_.iters                                   */
+    int nb;             /* boundaries_.size()                                  */
+    const int *btype;   /* boundaries_[b].type (nb)                            */
+    const int *bptr;    /* offsets into bpts/bvals (nb+1)                      */
+    const int *bpts;    /* boundaries_[b].bcPoints, concatenated               */
+    const double *bvals;/* boundaries_[b].values, concatenated                 */
+} orc_level;
+
+/* Column-major transfer matrix == reference `Eigen::SparseMatrix<double>`. */
+typedef struct {
+    int rows, cols;
+    const int *colptr;  /* cols+1 */
+    const int *rowidx;
+    const double *val;
+} orc_csc;
+
+void orc_boundary_op(orc_level *g, int coarse);
+void orc_modify_coeff_neumann(orc_level *g, int coarse);
+void orc_fix_vector_bound_coarse(const orc_level *g, double *vec);
+void orc_bound_eval_neumann(orc_level *g);
+void orc_sor(orc_level *g);
+/* one relaxation sweep (row loop + bound_eval_neumann), i.e. one `it` of sor */
+void orc_sor_sweeps(orc_level *g, int nsweeps);
+void orc_residual(const orc_level *g, double *r);
+double orc_l1(const double *v, int n);
+double orc_mg_residual(const orc_level *fine, double *work);
+void orc_csc_spmv(const orc_csc *m, const double *x, double *y);
+/* Multigrid::vCycle (frac_step=0) / FractionalStepMultigrid::vCycle (=1).
+ * Returns the relative L1 residual BEFORE the cycle (what the reference pushes
+ * into residuals_); returns -1 for the frac-step single-grid early-out. */
+double orc_vcycle(orc_level *levels, int nlevels, const orc_csc *R,
+                  const orc_csc *P, int frac_step);
+
+/* Block-hybrid schedule used by the multi-GPU "fast" mode: the rows are split
+ * into `nparts` owner ranges by part[i]; within a sweep a row sees the CURRENT
+ * sweep's values only for columns of its own part, and the values from the end
+ * of the previous sweep for all other parts (ghosts refreshed once per sweep). */
+void orc_sor_hybrid(orc_level *g, const int *part, int nparts, int nsweeps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
