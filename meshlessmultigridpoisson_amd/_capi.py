@@ -1,0 +1,317 @@
+"""ctypes binding of libmmgp.so (include/mmgp.h).
+
+Plumbing only: every class below is a thin handle wrapper whose methods call one
+C-ABI entry point.  There is no Python/NumPy compute path: if the shared library
+is missing, or no HIP device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmmgp.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+
+
+class LevelDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("a_size", C.c_int), ("rowptr", _ip), ("col", _ip), ("val", _dp),
+                ("bcflags", _ip), ("neumann_flag", C.c_int), ("omega", C.c_double), ("iters", C.c_int),
+                ("nb", C.c_int), ("btype", _ip), ("bptr", _ip), ("bpts", _ip), ("bvals", _dp),
+                ("tile_ptr", _ip), ("n_tiles", C.c_int), ("tile_size", C.c_int), ("lanes_per_row", C.c_int)]
+
+
+class LevelInfo(C.Structure):
+    _fields_ = [("n_tiles", C.c_int), ("n_phases", C.c_int), ("n_groups", C.c_int), ("lanes_per_row", C.c_int),
+                ("max_lds_bytes", C.c_int), ("sor_rows", C.c_longlong), ("sor_nnz", C.c_longlong),
+                ("stream_bytes", C.c_longlong), ("halo_entries", C.c_longlong), ("neumann_rows", C.c_longlong)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+#: every symbol include/mmgp.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
+    "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
+    "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
+    "mmg_level_sor", "mmg_level_sweeps", "mmg_level_bound_eval_neumann", "mmg_level_residual",
+    "mmg_level_residual_ratio", "mmg_level_boundary_op", "mmg_level_modify_coeff_neumann", "mmg_level_zero_x",
+    "mmg_level_time_sweeps", "mmg_level_time_residual", "mmg_transfer_create", "mmg_transfer_destroy",
+    "mmg_restrict", "mmg_prolong_add", "mmg_hierarchy_create", "mmg_hierarchy_destroy", "mmg_vcycle",
+    "mmg_hierarchy_residual", "mmg_vcycles", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply",
+]
+
+_lib = None
+
+
+class MmgError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmmgp.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MmgError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C meshlessmultigridpoisson_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        L.mmg_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        L.mmg_level_create.argtypes = [C.POINTER(vp), C.POINTER(LevelDesc)]
+        L.mmg_level_destroy.argtypes = [vp]
+        L.mmg_level_destroy.restype = None
+        L.mmg_level_info_get.argtypes = [vp, C.POINTER(LevelInfo)]
+        for f in ("mmg_level_set_x", "mmg_level_get_x", "mmg_level_set_rhs", "mmg_level_get_rhs",
+                  "mmg_level_set_bvals", "mmg_level_residual"):
+            getattr(L, f).argtypes = [vp, _dp, C.c_int]
+        L.mmg_level_set_omega_iters.argtypes = [vp, C.c_double, C.c_int]
+        for f in ("mmg_level_sor", "mmg_level_bound_eval_neumann", "mmg_level_zero_x"):
+            getattr(L, f).argtypes = [vp]
+        for f in ("mmg_level_sweeps", "mmg_level_boundary_op", "mmg_level_modify_coeff_neumann"):
+            getattr(L, f).argtypes = [vp, C.c_int]
+        L.mmg_level_residual_ratio.argtypes = [vp, _dp]
+        L.mmg_level_time_sweeps.argtypes = [vp, C.c_int, C.c_int, _fp]
+        L.mmg_level_time_residual.argtypes = [vp, C.c_int, _fp]
+        L.mmg_transfer_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _ip, _ip, _dp, C.c_int]
+        L.mmg_transfer_destroy.argtypes = [vp]
+        L.mmg_transfer_destroy.restype = None
+        L.mmg_restrict.argtypes = [vp, vp, vp]
+        L.mmg_prolong_add.argtypes = [vp, vp, vp]
+        L.mmg_hierarchy_create.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(vp), C.POINTER(vp), C.c_int]
+        L.mmg_hierarchy_destroy.argtypes = [vp]
+        L.mmg_hierarchy_destroy.restype = None
+        L.mmg_vcycle.argtypes = [vp, _dp]
+        L.mmg_hierarchy_residual.argtypes = [vp, _dp]
+        L.mmg_vcycles.argtypes = [vp, C.c_int, _dp, _fp]
+        L.mmg_spmv_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _ip, _ip, _dp]
+        L.mmg_spmv_destroy.argtypes = [vp]
+        L.mmg_spmv_destroy.restype = None
+        L.mmg_spmv_apply.argtypes = [vp, _dp, C.c_int, _dp, C.c_int]
+        L.mmg_set_stream.argtypes = [vp]
+        L.mmg_set_device.argtypes = [C.c_int]
+        L.mmg_device_count.argtypes = [_ip]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MmgError(f"libmmgp error {rc}: {lib().mmg_last_error().decode()}")
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().mmg_device_count(C.byref(n))
+    return n.value
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip) if a is not None and a.size else None
+
+
+def _pd(a):
+    return a.ctypes.data_as(_dp) if a is not None and a.size else None
+
+
+def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
+              tile_ptr=None, tile_size=0, lanes_per_row=0):
+    """Returns (LevelDesc, keepalive) -- keepalive holds the numpy arrays."""
+    keep = dict(rowptr=_i(rowptr), col=_i(col), val=_d(val), bcflags=_i(bcflags), btype=_i(btype),
+                bptr=_i(bptr), bpts=_i(bpts), bvals=_d(bvals))
+    d = LevelDesc()
+    d.n = int(n)
+    d.a_size = len(keep["rowptr"]) - 1
+    d.rowptr, d.col, d.val = _pi(keep["rowptr"]), _pi(keep["col"]), _pd(keep["val"])
+    d.bcflags = _pi(keep["bcflags"])
+    d.neumann_flag = int(bool(neumann))
+    d.omega, d.iters = float(omega), int(iters)
+    d.nb = len(keep["btype"])
+    d.btype, d.bptr = _pi(keep["btype"]), keep["bptr"].ctypes.data_as(_ip)
+    d.bpts, d.bvals = _pi(keep["bpts"]), _pd(keep["bvals"])
+    if tile_ptr is not None:
+        keep["tile_ptr"] = _i(tile_ptr)
+        d.tile_ptr = _pi(keep["tile_ptr"])
+        d.n_tiles = len(keep["tile_ptr"]) - 1
+    d.tile_size = int(tile_size)
+    d.lanes_per_row = int(lanes_per_row)
+    return d, keep
+
+
+class Level:
+    """Device-side counterpart of one reference `Grid` (hot methods only)."""
+
+    def __init__(self, n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
+                 x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0):
+        d, keep = make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
+                            tile_ptr, tile_size, lanes_per_row)
+        self.n, self.a_size = d.n, d.a_size
+        self.h = C.c_void_p()
+        check(lib().mmg_level_create(C.byref(self.h), C.byref(d)))
+        if x is not None:
+            self.set_x(x)
+        if b is not None:
+            self.set_rhs(b)
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmg_level_destroy(self.h)
+            self.h = None
+
+    def info(self):
+        inf = LevelInfo()
+        check(lib().mmg_level_info_get(self.h, C.byref(inf)))
+        return inf.as_dict()
+
+    def set_x(self, x):
+        x = _d(x)
+        check(lib().mmg_level_set_x(self.h, _pd(x), len(x)))
+
+    def get_x(self):
+        x = np.zeros(self.a_size)
+        check(lib().mmg_level_get_x(self.h, _pd(x), len(x)))
+        return x
+
+    def set_rhs(self, b):
+        b = _d(b)
+        check(lib().mmg_level_set_rhs(self.h, _pd(b), len(b)))
+
+    def get_rhs(self):
+        b = np.zeros(self.a_size)
+        check(lib().mmg_level_get_rhs(self.h, _pd(b), len(b)))
+        return b
+
+    def set_bvals(self, bvals):
+        v = _d(bvals)
+        check(lib().mmg_level_set_bvals(self.h, _pd(v), len(v)))
+
+    def sor(self):
+        check(lib().mmg_level_sor(self.h))
+
+    def sweeps(self, k):
+        check(lib().mmg_level_sweeps(self.h, int(k)))
+
+    def bound_eval_neumann(self):
+        check(lib().mmg_level_bound_eval_neumann(self.h))
+
+    def residual(self):
+        r = np.zeros(self.a_size)
+        check(lib().mmg_level_residual(self.h, _pd(r), len(r)))
+        return r
+
+    def residual_ratio(self):
+        v = C.c_double(0)
+        check(lib().mmg_level_residual_ratio(self.h, C.byref(v)))
+        return v.value
+
+    def boundary_op(self, coarse):
+        check(lib().mmg_level_boundary_op(self.h, int(coarse)))
+
+    def modify_coeff_neumann(self, coarse):
+        check(lib().mmg_level_modify_coeff_neumann(self.h, int(coarse)))
+
+    def zero_x(self):
+        check(lib().mmg_level_zero_x(self.h))
+
+    def time_sweeps(self, nsweeps, reps):
+        ms = np.zeros(reps, dtype=np.float32)
+        check(lib().mmg_level_time_sweeps(self.h, int(nsweeps), int(reps), ms.ctypes.data_as(_fp)))
+        return ms
+
+    def time_residual(self, reps):
+        ms = np.zeros(reps, dtype=np.float32)
+        check(lib().mmg_level_time_residual(self.h, int(reps), ms.ctypes.data_as(_fp)))
+        return ms
+
+
+class Transfer:
+    def __init__(self, rows, cols, outer, inner, val, col_major=True):
+        outer, inner, val = _i(outer), _i(inner), _d(val)
+        self.h = C.c_void_p()
+        check(lib().mmg_transfer_create(C.byref(self.h), int(rows), int(cols), _pi(outer), _pi(inner), _pd(val),
+                                        int(col_major)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmg_transfer_destroy(self.h)
+            self.h = None
+
+
+def restrict(fine: Level, coarse: Level, R: Transfer):
+    check(lib().mmg_restrict(fine.h, coarse.h, R.h))
+
+
+def prolong_add(coarse: Level, fine: Level, P: Transfer):
+    check(lib().mmg_prolong_add(coarse.h, fine.h, P.h))
+
+
+class Hierarchy:
+    """Device-side counterpart of the reference `Multigrid` (coarse -> fine)."""
+
+    def __init__(self, levels, R, P, frac_step=False):
+        self.levels, self.R, self.P = list(levels), list(R), list(P)
+        nl = len(levels)
+        vp = C.c_void_p
+        la = (vp * nl)(*[l.h for l in levels])
+        ra = (vp * nl)(*[(r.h if r is not None else None) for r in R])
+        pa = (vp * nl)(*[(p.h if p is not None else None) for p in P])
+        self.h = C.c_void_p()
+        check(lib().mmg_hierarchy_create(C.byref(self.h), la, nl, ra, pa, int(frac_step)))
+        self.residuals = []
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmg_hierarchy_destroy(self.h)
+            self.h = None
+
+    def vcycle(self):
+        v = C.c_double(0)
+        check(lib().mmg_vcycle(self.h, C.byref(v)))
+        if v.value >= 0:
+            self.residuals.append(v.value)
+        return v.value
+
+    def vcycles(self, n):
+        res = np.zeros(n)
+        ms = C.c_float(0)
+        check(lib().mmg_vcycles(self.h, int(n), _pd(res), C.byref(ms)))
+        self.residuals.extend(float(r) for r in res if r >= 0)
+        return res, ms.value
+
+    def residual(self):
+        v = C.c_double(0)
+        check(lib().mmg_hierarchy_residual(self.h, C.byref(v)))
+        return v.value
+
+
+class Spmv:
+    def __init__(self, rows, cols, rowptr, col, val):
+        rowptr, col, val = _i(rowptr), _i(col), _d(val)
+        self.rows, self.cols = int(rows), int(cols)
+        self.h = C.c_void_p()
+        check(lib().mmg_spmv_create(C.byref(self.h), self.rows, self.cols, _pi(rowptr), _pi(col), _pd(val)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmg_spmv_destroy(self.h)
+            self.h = None
+
+    def apply(self, x):
+        x = _d(x)
+        y = np.zeros(self.rows)
+        check(lib().mmg_spmv_apply(self.h, _pd(x), len(x), _pd(y), len(y)))
+        return y

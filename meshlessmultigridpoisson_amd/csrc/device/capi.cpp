@@ -1,0 +1,779 @@
+// capi.cpp -- implementation of include/mmgp.h on top of the packed plans and
+// the gfx950 kernels.  Host logic only (built by hipcc for the HIP runtime API).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/mmgp.h"
+#include "kernels.hpp"
+#include "level_plan.hpp"
+#include "plan.hpp"
+
+using namespace mmg;
+
+// ---------------------------------------------------------------------------
+// error / device / stream state
+// ---------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+thread_local hipStream_t g_stream = nullptr;
+thread_local bool g_own_stream = false;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPC(call)                                                                                 \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(MMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+int ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) return fail(MMG_ERR_NO_DEVICE, "no HIP device (libmmgp has no CPU fallback)");
+    if (!g_stream) {
+        HIPC(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        g_own_stream = true;
+    }
+    return MMG_OK;
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+    }
+    hipError_t upload(const T *src, size_t count)
+    {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || count == 0) return e;
+        return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct PlanGpu {
+    DevBuf<TileDesc> tiles;
+    DevBuf<int32_t> halo;
+    DevBuf<uint32_t> ghead;
+    DevBuf<uint8_t> stream;
+    DevBuf<int32_t> phase_tiles;
+    std::vector<int32_t> phase_ptr;
+    PlanDev dev;
+    int n_tiles = 0;
+    long long n_rows = 0, n_nnz = 0, n_groups = 0, stream_bytes = 0, halo_entries = 0;
+    int max_lds = 0;
+    bool empty() const { return n_rows == 0; }
+    int n_phases() const { return (int)phase_ptr.size() - 1; }
+
+    int upload(const Plan &P)
+    {
+        HIPC(tiles.upload(P.tiles.data(), P.tiles.size()));
+        HIPC(halo.upload(P.halo.data(), P.halo.size()));
+        HIPC(ghead.upload(P.ghead.data(), P.ghead.size()));
+        HIPC(stream.upload(P.stream.data(), P.stream.size()));
+        HIPC(phase_tiles.upload(P.phase_tiles.data(), P.phase_tiles.size()));
+        phase_ptr = P.phase_ptr;
+        n_tiles = P.n_tiles;
+        n_rows = P.n_rows;
+        n_nnz = P.n_nnz;
+        n_groups = P.n_groups;
+        stream_bytes = (long long)P.stream.size();
+        halo_entries = (long long)P.halo.size();
+        max_lds = (int)P.lds_bytes();
+        dev.tiles = tiles.p;
+        dev.halo = halo.p;
+        dev.ghead = ghead.p;
+        dev.stream = stream.p;
+        dev.phase_tiles = phase_tiles.p;
+        dev.L = P.L;
+        dev.n_tiles = P.n_tiles;
+        dev.lds_bytes = (unsigned)P.lds_bytes();
+        return MMG_OK;
+    }
+};
+
+int pick_L(int L) { return L > 0 ? L : 4; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct mmg_level {
+    int n = 0, a_size = 0, neumann = 0, iters = 0;
+    double omega = 1.0;
+    DevBuf<double> x, b, r;
+    DevBuf<uint8_t> flags8;
+    PlanGpu A;  // interior rows: relaxation + residual
+    PlanGpu B;  // Neumann boundary rows: bound_eval_neumann + residual
+    // boundary bookkeeping (host copies kept for set_bvals)
+    std::vector<int> btype, bptr, bpts;
+    std::vector<int32_t> dir_idx_h, neu_idx_h;       // deduplicated scatter targets
+    std::vector<int32_t> dir_src_h, neu_src_h;       // position in bvals of each target
+    DevBuf<int32_t> dir_idx, neu_idx;
+    DevBuf<double> dir_vals, neu_vals;
+    DevBuf<double> partA, partX, partB, partBn, scal;
+    int n_absb = 0;
+};
+
+struct mmg_transfer {
+    int rows = 0, cols = 0;
+    std::vector<int> rowptr, col;
+    std::vector<double> val;
+    PlanGpu all;                                   // every row (restriction, or unmasked prolongation)
+    std::vector<std::pair<const mmg_level *, std::unique_ptr<PlanGpu>>> masked;  // prolongation skipping Dirichlet rows
+};
+
+struct mmg_hierarchy {
+    std::vector<mmg_level *> lv;
+    std::vector<mmg_transfer *> R, P;
+    int frac_step = 0;
+};
+
+struct mmg_spmv {
+    int rows = 0, cols = 0;
+    PlanGpu plan;
+    DevBuf<double> x, y;
+};
+
+namespace {
+
+int build_gather_plan(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows, bool diag, bool self,
+                      bool in_place, int mult_col, PlanGpu *out)
+{
+    Plan P;
+    const std::string err = build_gather_plan_host(A, rows, L, tile_rows, diag, self, in_place, mult_col, &P);
+    if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "plan: " + err);
+    return out->upload(P);
+}
+
+int sweep_once(mmg_level *lv)
+{
+    TileArgs a{};
+    a.p = lv->A.dev;
+    a.in = lv->x.p;
+    a.out = lv->x.p;
+    a.b = lv->b.p;
+    a.omega = lv->omega;
+    a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
+    a.flags8 = lv->flags8.p;
+    a.partial = lv->neumann ? lv->partX.p : nullptr;
+    for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
+        a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
+        a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+        HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+    }
+    if (lv->neumann)
+        HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+    return MMG_OK;
+}
+
+int bound_eval(mmg_level *lv)
+{
+    if (lv->B.empty()) return MMG_OK;
+    TileArgs a{};
+    a.p = lv->B.dev;
+    a.in = lv->x.p;
+    a.out = lv->x.p;
+    a.b = lv->b.p;
+    for (int ph = 0; ph < lv->B.n_phases(); ++ph) {
+        a.tile_list = lv->B.dev.phase_tiles + lv->B.phase_ptr[ph];
+        a.n_list = lv->B.phase_ptr[ph + 1] - lv->B.phase_ptr[ph];
+        HIPC(launch_tile_kernel(MODE_BOUND, a, g_stream));
+    }
+    return MMG_OK;
+}
+
+int sweeps(mmg_level *lv, int k)
+{
+    for (int it = 0; it < k; ++it) {
+        int rc = sweep_once(lv);
+        if (rc) return rc;
+        rc = bound_eval(lv);
+        if (rc) return rc;
+    }
+    return MMG_OK;
+}
+
+// r = b - A x with Dirichlet rows zeroed; scal[0] = ||r||_1, scal[1] = ||b||_1
+int residual_dev(mmg_level *lv, bool norms)
+{
+    TileArgs a{};
+    a.p = lv->A.dev;
+    a.tile_list = nullptr;
+    a.n_list = lv->A.n_tiles;
+    a.in = lv->x.p;
+    a.out = lv->r.p;
+    a.b = lv->b.p;
+    a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
+    a.flags8 = lv->flags8.p;
+    a.partial = lv->partA.p;
+    a.partial2 = lv->neumann ? lv->partX.p : nullptr;
+    HIPC(launch_tile_kernel(MODE_RESID, a, g_stream));
+    if (!lv->B.empty()) {
+        TileArgs c{};
+        c.p = lv->B.dev;
+        c.n_list = lv->B.n_tiles;
+        c.in = lv->x.p;
+        c.out = lv->r.p;
+        c.b = lv->b.p;
+        c.partial = lv->partB.p;
+        HIPC(launch_tile_kernel(MODE_RESID, c, g_stream));
+    }
+    HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
+    if (norms) HIPC(launch_abs_sum(lv->b.p, lv->a_size, lv->partBn.p, g_stream));
+    HIPC(launch_resid_finalize(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
+                               lv->partBn.p, norms ? lv->n_absb : 0, lv->partX.p, lv->A.n_tiles, lv->x.p, lv->b.p,
+                               lv->r.p, lv->n, lv->neumann, lv->scal.p, g_stream));
+    return MMG_OK;
+}
+
+int residual_ratio(mmg_level *lv, double *ratio)
+{
+    int rc = residual_dev(lv, true);
+    if (rc) return rc;
+    double h[2];
+    HIPC(hipMemcpyAsync(h, lv->scal.p, sizeof(h), hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    *ratio = h[0] / h[1];
+    return MMG_OK;
+}
+
+int boundary_op(mmg_level *lv, int coarse)
+{
+    if (lv->dir_idx.n == 0) return MMG_OK;
+    if (coarse) HIPC(launch_scatter_const(lv->x.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
+    else HIPC(launch_scatter_vals(lv->x.p, lv->dir_idx.p, lv->dir_vals.p, (int)lv->dir_idx.n, g_stream));
+    return MMG_OK;
+}
+
+int modify_coeff_neumann(mmg_level *lv, int coarse)
+{
+    if (lv->neu_idx.n) {
+        if (coarse) HIPC(launch_scatter_const(lv->b.p, lv->neu_idx.p, (int)lv->neu_idx.n, 0.0, g_stream));
+        else HIPC(launch_scatter_vals(lv->b.p, lv->neu_idx.p, lv->neu_vals.p, (int)lv->neu_idx.n, g_stream));
+    }
+    HIPC(launch_fill(lv->b.p + (lv->a_size - 1), 1, 0.0, g_stream));  // grid.cpp:71, unconditional
+    return MMG_OK;
+}
+
+int upload_bvals(mmg_level *lv, const double *bvals)
+{
+    std::vector<double> dv(lv->dir_idx_h.size()), nv(lv->neu_idx_h.size());
+    for (size_t i = 0; i < dv.size(); ++i) dv[i] = bvals[lv->dir_src_h[i]];
+    for (size_t i = 0; i < nv.size(); ++i) nv[i] = bvals[lv->neu_src_h[i]];
+    HIPC(lv->dir_vals.upload(dv.data(), dv.size()));
+    HIPC(lv->neu_vals.upload(nv.data(), nv.size()));
+    return MMG_OK;
+}
+
+int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
+{
+    if (R->rows != coarse->n || R->cols != fine->n) return fail(MMG_ERR_INVALID, "restrict: shape mismatch");
+    int rc = residual_dev(fine, false);
+    if (rc) return rc;
+    TileArgs a{};
+    a.p = R->all.dev;
+    a.n_list = R->all.n_tiles;
+    a.in = fine->r.p;
+    a.out = coarse->b.p;
+    HIPC(launch_tile_kernel(MODE_SET, a, g_stream));
+    HIPC(launch_scatter_const(coarse->b.p, coarse->dir_idx.p, (int)coarse->dir_idx.n, 0.0, g_stream));
+    if (fine->neumann) {
+        HIPC(launch_fill(coarse->b.p + (coarse->a_size - 1), 1, 0.0, g_stream));
+        rc = modify_coeff_neumann(coarse, 1);
+        if (rc) return rc;
+    }
+    return MMG_OK;
+}
+
+int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
+{
+    if (P->rows != fine->n || P->cols != coarse->n) return fail(MMG_ERR_INVALID, "prolong: shape mismatch");
+    PlanGpu *plan = &P->all;
+    if (!fine->neumann && !fine->dir_idx_h.empty()) {  // multigrid.cpp:103-105
+        plan = nullptr;
+        for (auto &m : P->masked)
+            if (m.first == fine) plan = m.second.get();
+        if (!plan) {
+            std::vector<uint8_t> skip((size_t)fine->n, 0);
+            for (int32_t i : fine->dir_idx_h) skip[i] = 1;
+            std::vector<int32_t> rows;
+            for (int i = 0; i < fine->n; ++i)
+                if (!skip[i]) rows.push_back(i);
+            auto pg = std::make_unique<PlanGpu>();
+            CsrView A{P->rows, P->cols, P->rowptr.data(), P->col.data(), P->val.data()};
+            int rc = build_gather_plan(A, rows, P->all.dev.L, 256, false, false, false, -1, pg.get());
+            if (rc) return rc;
+            plan = pg.get();
+            P->masked.emplace_back(fine, std::move(pg));
+        }
+    }
+    TileArgs a{};
+    a.p = plan->dev;
+    a.n_list = plan->n_tiles;
+    a.in = coarse->x.p;
+    a.out = fine->x.p;
+    HIPC(launch_tile_kernel(MODE_ADD, a, g_stream));
+    return MMG_OK;
+}
+
+int vcycle_dev(mmg_hierarchy *h, double *resid_before)
+{
+    const int nl = (int)h->lv.size();
+    mmg_level *fine = h->lv[nl - 1];
+    int rc;
+    if (h->frac_step && nl == 1) {  // FracStepMultigrid.cpp:64-67
+        *resid_before = -1.0;
+        return sweeps(fine, fine->iters);
+    }
+    if ((rc = residual_ratio(fine, resid_before))) return rc;  // multigrid.cpp:66
+    if ((rc = bound_eval(fine))) return rc;                    // :68
+    mmg_level *curr = fine;
+    for (int i = nl - 1; i > 0; --i) {  // :71-88
+        curr = h->lv[i];
+        if (i != nl - 1) HIPC(launch_fill(curr->x.p, curr->a_size, 0.0, g_stream));
+        if ((rc = boundary_op(curr, i != nl - 1))) return rc;
+        if ((rc = sweeps(curr, curr->iters))) return rc;
+        if ((rc = do_restrict(curr, h->lv[i - 1], h->R[i]))) return rc;
+    }
+    if ((rc = boundary_op(curr, 1))) return rc;  // :91 (quirk N6: still the last loop grid)
+    curr = h->lv[0];
+    HIPC(launch_fill(curr->x.p, curr->a_size, 0.0, g_stream));
+    if ((rc = sweeps(curr, curr->iters))) return rc;
+    if ((rc = sweeps(curr, curr->iters))) return rc;
+    for (int i = 1; i < nl; ++i) {  // :99-109
+        curr = h->lv[i];
+        if ((rc = do_prolong(h->lv[i - 1], curr, h->P[i - 1]))) return rc;
+        if ((rc = sweeps(curr, curr->iters))) return rc;
+    }
+    return MMG_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *mmg_last_error(void) { return g_err.c_str(); }
+
+int mmg_device_count(int *count)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (count) *count = n;
+    return MMG_OK;
+}
+
+int mmg_set_device(int device)
+{
+    HIPC(hipSetDevice(device));
+    return MMG_OK;
+}
+
+int mmg_set_stream(void *hip_stream)
+{
+    if (g_own_stream && g_stream) (void)hipStreamDestroy(g_stream);
+    g_own_stream = false;
+    g_stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!g_stream) return ensure_device();
+    return MMG_OK;
+}
+
+int mmg_synchronize(void)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
+{
+    if (!out || !d) return fail(MMG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (d->n < 1 || d->a_size != d->n + (d->neumann_flag ? 1 : 0) || !d->rowptr || !d->col || !d->val || !d->bcflags)
+        return fail(MMG_ERR_INVALID, "level_create: inconsistent sizes");
+    if (d->nb < 0 || (d->nb > 0 && (!d->btype || !d->bptr || !d->bpts || !d->bvals)))
+        return fail(MMG_ERR_INVALID, "level_create: boundary arrays missing");
+    const int n = d->n;
+    const int L = pick_L(d->lanes_per_row);
+    auto lv = std::make_unique<mmg_level>();
+    lv->n = n;
+    lv->a_size = d->a_size;
+    lv->neumann = d->neumann_flag ? 1 : 0;
+    lv->omega = d->omega;
+    lv->iters = d->iters;
+
+    {
+        const std::string merr = check_multiplier(*d);
+        if (!merr.empty()) return fail(MMG_ERR_UNSUPPORTED, merr);
+    }
+    // ---- boundaries: deduplicated scatter lists, last writer wins (sequential semantics)
+    lv->btype.assign(d->btype, d->btype + d->nb);
+    lv->bptr.assign(d->bptr, d->bptr + d->nb + 1);
+    const int nbp = d->nb ? d->bptr[d->nb] : 0;
+    lv->bpts.assign(d->bpts, d->bpts + nbp);
+    BoundaryLists bl;
+    {
+        const std::string berr = build_boundary_lists(*d, &bl);
+        if (!berr.empty()) return fail(MMG_ERR_INVALID, berr);
+    }
+    lv->dir_idx_h = bl.dir_idx;
+    lv->dir_src_h = bl.dir_src;
+    lv->neu_idx_h = bl.neu_idx;
+    lv->neu_src_h = bl.neu_src;
+    const std::vector<int32_t> &neu_rows = bl.neu_rows;
+    HIPC(lv->dir_idx.upload(lv->dir_idx_h.data(), lv->dir_idx_h.size()));
+    HIPC(lv->neu_idx.upload(lv->neu_idx_h.data(), lv->neu_idx_h.size()));
+    if ((rc = upload_bvals(lv.get(), d->bvals))) return rc;
+
+    // ---- plan A: interior rows, own range = the tile's points ------------------
+    CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
+    {
+        Plan P;
+        const std::string err = build_level_plan(*d, L, &P);
+        if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
+        if ((rc = lv->A.upload(P))) return rc;
+    }
+
+    // ---- plan B: Neumann rows --------------------------------------------------
+    if (!neu_rows.empty()) {
+        if ((rc = build_gather_plan(A, neu_rows, L, 64, true, true, true, -1, &lv->B))) return rc;
+    }
+
+    // ---- vectors ---------------------------------------------------------------
+    std::vector<uint8_t> f8((size_t)n);
+    for (int i = 0; i < n; ++i) f8[i] = (uint8_t)d->bcflags[i];
+    HIPC(lv->flags8.upload(f8.data(), f8.size()));
+    HIPC(lv->x.alloc((size_t)d->a_size));
+    HIPC(lv->b.alloc((size_t)d->a_size));
+    HIPC(lv->r.alloc((size_t)d->a_size));
+    HIPC(hipMemset(lv->x.p, 0, sizeof(double) * (size_t)d->a_size));
+    HIPC(hipMemset(lv->b.p, 0, sizeof(double) * (size_t)d->a_size));
+    HIPC(hipMemset(lv->r.p, 0, sizeof(double) * (size_t)d->a_size));
+    HIPC(lv->partA.alloc((size_t)lv->A.n_tiles));
+    HIPC(lv->partX.alloc((size_t)lv->A.n_tiles));
+    HIPC(lv->partB.alloc((size_t)std::max(1, lv->B.n_tiles)));
+    lv->n_absb = abs_sum_blocks(d->a_size);
+    HIPC(lv->partBn.alloc((size_t)std::max(1, lv->n_absb)));
+    HIPC(lv->scal.alloc(2));
+    HIPC(hipMemset(lv->partA.p, 0, sizeof(double) * lv->partA.n));
+    HIPC(hipMemset(lv->partX.p, 0, sizeof(double) * lv->partX.n));
+    HIPC(hipMemset(lv->partB.p, 0, sizeof(double) * lv->partB.n));
+    *out = lv.release();
+    return MMG_OK;
+}
+
+void mmg_level_destroy(mmg_level *lv) { delete lv; }
+
+int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info)
+{
+    if (!lv || !info) return fail(MMG_ERR_INVALID, "null argument");
+    info->n_tiles = lv->A.n_tiles;
+    info->n_phases = lv->A.n_phases();
+    info->n_groups = (int)lv->A.n_groups;
+    info->lanes_per_row = lv->A.dev.L;
+    info->max_lds_bytes = lv->A.max_lds;
+    info->sor_rows = lv->A.n_rows;
+    info->sor_nnz = lv->A.n_nnz;
+    info->stream_bytes = lv->A.stream_bytes;
+    info->halo_entries = lv->A.halo_entries;
+    info->neumann_rows = lv->B.n_rows;
+    return MMG_OK;
+}
+
+#define LEVEL_VEC_IO(name, member, dir)                                                              \
+    int name(mmg_level *lv, dir double *v, int count)                                                \
+    {                                                                                                \
+        if (!lv || !v || count != lv->a_size) return fail(MMG_ERR_INVALID, #name ": bad size");      \
+        int rc = ensure_device();                                                                    \
+        if (rc) return rc;
+
+LEVEL_VEC_IO(mmg_level_set_x, x, const)
+    HIPC(hipMemcpyAsync(lv->x.p, v, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+LEVEL_VEC_IO(mmg_level_get_x, x, )
+    HIPC(hipMemcpyAsync(v, lv->x.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+LEVEL_VEC_IO(mmg_level_set_rhs, b, const)
+    HIPC(hipMemcpyAsync(lv->b.p, v, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+LEVEL_VEC_IO(mmg_level_get_rhs, b, )
+    HIPC(hipMemcpyAsync(v, lv->b.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+int mmg_level_set_bvals(mmg_level *lv, const double *bvals, int count)
+{
+    if (!lv || !bvals || count != (int)lv->bpts.size()) return fail(MMG_ERR_INVALID, "set_bvals: bad size");
+    HIPC(hipStreamSynchronize(g_stream));
+    return upload_bvals(lv, bvals);
+}
+
+int mmg_level_set_omega_iters(mmg_level *lv, double omega, int iters)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    lv->omega = omega;
+    lv->iters = iters;
+    return MMG_OK;
+}
+
+int mmg_level_sor(mmg_level *lv)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    return sweeps(lv, lv->iters);
+}
+int mmg_level_sweeps(mmg_level *lv, int nsweeps)
+{
+    if (!lv || nsweeps < 0) return fail(MMG_ERR_INVALID, "bad argument");
+    return sweeps(lv, nsweeps);
+}
+int mmg_level_bound_eval_neumann(mmg_level *lv)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    return bound_eval(lv);
+}
+int mmg_level_residual(mmg_level *lv, double *r_out, int count)
+{
+    if (!lv || (r_out && count != lv->a_size)) return fail(MMG_ERR_INVALID, "residual: bad size");
+    int rc = residual_dev(lv, false);
+    if (rc) return rc;
+    if (r_out) {
+        HIPC(hipMemcpyAsync(r_out, lv->r.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+    }
+    return MMG_OK;
+}
+int mmg_level_residual_ratio(mmg_level *lv, double *ratio)
+{
+    if (!lv || !ratio) return fail(MMG_ERR_INVALID, "null argument");
+    return residual_ratio(lv, ratio);
+}
+int mmg_level_boundary_op(mmg_level *lv, int coarse)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    return boundary_op(lv, coarse);
+}
+int mmg_level_modify_coeff_neumann(mmg_level *lv, int coarse)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    return modify_coeff_neumann(lv, coarse);
+}
+int mmg_level_zero_x(mmg_level *lv)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    HIPC(launch_fill(lv->x.p, lv->a_size, 0.0, g_stream));
+    return MMG_OK;
+}
+
+int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
+{
+    if (!lv || !ms_out || reps < 1) return fail(MMG_ERR_INVALID, "bad argument");
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    int rc = MMG_OK;
+    for (int r = 0; r < reps && !rc; ++r) {
+        HIPC(hipEventRecord(e0, g_stream));
+        rc = sweeps(lv, nsweeps);
+        HIPC(hipEventRecord(e1, g_stream));
+        HIPC(hipEventSynchronize(e1));
+        HIPC(hipEventElapsedTime(&ms_out[r], e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out)
+{
+    if (!lv || !ms_out || reps < 1) return fail(MMG_ERR_INVALID, "bad argument");
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    int rc = MMG_OK;
+    for (int r = 0; r < reps && !rc; ++r) {
+        HIPC(hipEventRecord(e0, g_stream));
+        rc = residual_dev(lv, true);
+        HIPC(hipEventRecord(e1, g_stream));
+        HIPC(hipEventSynchronize(e1));
+        HIPC(hipEventElapsedTime(&ms_out[r], e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int mmg_transfer_create(mmg_transfer **out, int rows, int cols, const int *outer, const int *inner,
+                        const double *val, int col_major)
+{
+    if (!out || rows < 1 || cols < 1 || !outer || !inner || !val) return fail(MMG_ERR_INVALID, "transfer_create: bad argument");
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    auto t = std::make_unique<mmg_transfer>();
+    t->rows = rows;
+    t->cols = cols;
+    if (!col_major) {
+        const int nnz = outer[rows];
+        t->rowptr.assign(outer, outer + rows + 1);
+        t->col.assign(inner, inner + nnz);
+        t->val.assign(val, val + nnz);
+    } else {
+        const int nnz = outer[cols];
+        for (int p = 0; p < nnz; ++p)
+            if (inner[p] < 0 || inner[p] >= rows) return fail(MMG_ERR_INVALID, "transfer_create: row index out of range");
+        csc_to_csr(rows, cols, outer, inner, val, &t->rowptr, &t->col, &t->val);
+    }
+    std::vector<int32_t> rows_all((size_t)rows);
+    for (int i = 0; i < rows; ++i) rows_all[i] = i;
+    CsrView A{rows, cols, t->rowptr.data(), t->col.data(), t->val.data()};
+    if ((rc = build_gather_plan(A, rows_all, 4, 256, false, false, false, -1, &t->all))) return rc;
+    *out = t.release();
+    return MMG_OK;
+}
+
+void mmg_transfer_destroy(mmg_transfer *t) { delete t; }
+
+int mmg_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
+{
+    if (!fine || !coarse || !R) return fail(MMG_ERR_INVALID, "null argument");
+    return do_restrict(fine, coarse, R);
+}
+int mmg_prolong_add(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
+{
+    if (!fine || !coarse || !P) return fail(MMG_ERR_INVALID, "null argument");
+    return do_prolong(coarse, fine, P);
+}
+
+int mmg_hierarchy_create(mmg_hierarchy **out, mmg_level **levels, int nlevels, mmg_transfer **R, mmg_transfer **P,
+                         int frac_step)
+{
+    if (!out || !levels || nlevels < 1) return fail(MMG_ERR_INVALID, "hierarchy_create: bad argument");
+    auto h = std::make_unique<mmg_hierarchy>();
+    for (int i = 0; i < nlevels; ++i) {
+        if (!levels[i]) return fail(MMG_ERR_INVALID, "hierarchy_create: null level");
+        h->lv.push_back(levels[i]);
+        h->R.push_back(R ? R[i] : nullptr);
+        h->P.push_back(P ? P[i] : nullptr);
+    }
+    for (int i = 1; i < nlevels; ++i)
+        if (!h->R[i] || !h->P[i - 1]) return fail(MMG_ERR_INVALID, "hierarchy_create: missing transfer");
+    h->frac_step = frac_step;
+    *out = h.release();
+    return MMG_OK;
+}
+void mmg_hierarchy_destroy(mmg_hierarchy *h) { delete h; }
+
+int mmg_vcycle(mmg_hierarchy *h, double *resid_before)
+{
+    if (!h) return fail(MMG_ERR_INVALID, "null hierarchy");
+    double r = 0.0;
+    int rc = vcycle_dev(h, &r);
+    if (resid_before) *resid_before = r;
+    return rc;
+}
+int mmg_hierarchy_residual(mmg_hierarchy *h, double *ratio)
+{
+    if (!h || !ratio) return fail(MMG_ERR_INVALID, "null argument");
+    return residual_ratio(h->lv.back(), ratio);
+}
+int mmg_vcycles(mmg_hierarchy *h, int ncycles, double *resid, float *ms)
+{
+    if (!h || ncycles < 0) return fail(MMG_ERR_INVALID, "bad argument");
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, g_stream));
+    int rc = MMG_OK;
+    for (int c = 0; c < ncycles && !rc; ++c) {
+        double r = 0.0;
+        rc = vcycle_dev(h, &r);
+        if (resid) resid[c] = r;
+    }
+    HIPC(hipEventRecord(e1, g_stream));
+    HIPC(hipEventSynchronize(e1));
+    if (ms) HIPC(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int mmg_spmv_create(mmg_spmv **out, int rows, int cols, const int *rowptr, const int *col, const double *val)
+{
+    if (!out || rows < 1 || cols < 1 || !rowptr || !col || !val) return fail(MMG_ERR_INVALID, "spmv_create: bad argument");
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    auto m = std::make_unique<mmg_spmv>();
+    m->rows = rows;
+    m->cols = cols;
+    std::vector<int32_t> rows_all((size_t)rows);
+    for (int i = 0; i < rows; ++i) rows_all[i] = i;
+    CsrView A{rows, cols, rowptr, col, val};
+    if ((rc = build_gather_plan(A, rows_all, 4, 256, false, false, false, -1, &m->plan))) return rc;
+    HIPC(m->x.alloc((size_t)cols));
+    HIPC(m->y.alloc((size_t)rows));
+    *out = m.release();
+    return MMG_OK;
+}
+void mmg_spmv_destroy(mmg_spmv *m) { delete m; }
+
+int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny)
+{
+    if (!m || !x || !y || nx != m->cols || ny != m->rows) return fail(MMG_ERR_INVALID, "spmv_apply: bad size");
+    HIPC(hipMemcpyAsync(m->x.p, x, sizeof(double) * (size_t)nx, hipMemcpyHostToDevice, g_stream));
+    HIPC(hipMemsetAsync(m->y.p, 0, sizeof(double) * (size_t)ny, g_stream));  // rows without entries
+    TileArgs a{};
+    a.p = m->plan.dev;
+    a.n_list = m->plan.n_tiles;
+    a.in = m->x.p;
+    a.out = m->y.p;
+    HIPC(launch_tile_kernel(MODE_SET, a, g_stream));
+    HIPC(hipMemcpyAsync(y, m->y.p, sizeof(double) * (size_t)ny, hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+}  // extern "C"

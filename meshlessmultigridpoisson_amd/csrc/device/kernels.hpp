@@ -1,0 +1,58 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "plan.hpp"
+
+namespace mmg {
+
+struct PlanDev {
+    const TileDesc *tiles = nullptr;
+    const int32_t *halo = nullptr;
+    const uint32_t *ghead = nullptr;
+    const uint8_t *stream = nullptr;
+    const int32_t *phase_tiles = nullptr;
+    int L = 4;
+    int n_tiles = 0;
+    unsigned lds_bytes = 0;
+};
+
+enum TileMode {
+    MODE_SOR = 0,    // in-place relaxation of the own range (grid.cpp:122-141)
+    MODE_BOUND = 1,  // x_c = (b_c - sum_{k!=c} a_ck x_k) / a_cc (grid.cpp:84-98)
+    MODE_RESID = 2,  // r = b - A x (grid.cpp:148)
+    MODE_SET = 3,    // out = A in   (multigrid.cpp:81, fractionalStepGrid.cpp:103-150)
+    MODE_ADD = 4     // out += A in  (multigrid.cpp:102-106)
+};
+
+struct TileArgs {
+    PlanDev p;
+    const int32_t *tile_list;  // tiles of this launch (nullptr: 0..n_list-1)
+    int n_list;
+    const double *in;          // staged vector
+    double *out;
+    const double *b;           // right-hand side (SOR / BOUND / RESID)
+    double omega;
+    const double *lambda;      // multiplier value x[n] (nullptr: none)
+    const uint8_t *flags8;     // bcFlags per point (partial sums)
+    double *partial;           // per tile: SOR: sum of non-Neumann own x; RESID: sum |r|
+    double *partial2;          // RESID: sum of non-Neumann own x
+};
+
+hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
+
+hipError_t launch_fill(double *v, long long n, double c, hipStream_t s);
+hipError_t launch_scatter_const(double *v, const int32_t *idx, int n, double c, hipStream_t s);
+hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);
+// x[n] <- (1-w) x[n] + w (b[n] - sum(partial))            (grid.cpp:118-141, row N)
+hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial,
+                              double omega, hipStream_t s);
+// partial[block] = sum |v|
+int abs_sum_blocks(long long n);
+hipError_t launch_abs_sum(const double *v, long long n, double *partial, hipStream_t s);
+// out2[0] = sum(pa)+sum(pb)+|r_N| ; out2[1] = sum(pbn) ; writes r[n] when neumann
+hipError_t launch_resid_finalize(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
+                                 const double *px, int npx, const double *x, const double *b, double *r, int n,
+                                 int neumann, double *out2, hipStream_t s);
+
+}  // namespace mmg

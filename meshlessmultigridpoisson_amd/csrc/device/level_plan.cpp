@@ -1,0 +1,148 @@
+// level_plan.cpp -- see level_plan.hpp.
+#include "level_plan.hpp"
+
+#include <algorithm>
+
+namespace mmg {
+
+std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows,
+                                   bool diag, bool self, bool in_place, int mult_col, Plan *out)
+{
+    std::string err;
+    int tr = std::max(1, tile_rows);
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        std::vector<int64_t> tp = uniform_tile_ptr((int64_t)rows.size(), tr);
+        PlanSpec s;
+        s.A = A;
+        s.rows = rows.data();
+        s.n_rows = (int64_t)rows.size();
+        s.tile_ptr = tp.data();
+        s.n_tiles = (int)tp.size() - 1;
+        s.extract_diag = diag;
+        s.need_self = self;
+        s.in_place = in_place;
+        s.mult_col = mult_col;
+        s.L = L;
+        err = build_plan(s, out);
+        if (err.empty()) return err;
+        if (err.rfind("tile-too-large", 0) != 0 || tr == 1) break;
+        tr = std::max(1, tr / 2);
+    }
+    return err;
+}
+
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
+{
+    const int n = d.n;
+    CsrView A{d.a_size, d.a_size, d.rowptr, d.col, d.val};
+    std::vector<int32_t> pt_tile;
+    if (d.tile_ptr && d.n_tiles > 0) {
+        pt_tile.assign(d.tile_ptr, d.tile_ptr + d.n_tiles + 1);
+        if (pt_tile.front() != 0 || pt_tile.back() != n) return "tile_ptr must cover [0,n)";
+        for (size_t i = 1; i < pt_tile.size(); ++i)
+            if (pt_tile[i] < pt_tile[i - 1]) return "tile_ptr must be non-decreasing";
+    } else {
+        const int ts = d.tile_size > 0 ? d.tile_size : 512;
+        for (int p = 0; p < n; p += ts) pt_tile.push_back(p);
+        pt_tile.push_back(n);
+    }
+    std::vector<int32_t> rows;
+    rows.reserve(n);
+    for (int i = 0; i < n; ++i)
+        if (d.bcflags[i] == 0) rows.push_back(i);
+    std::string err;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        const int nt = (int)pt_tile.size() - 1;
+        std::vector<int64_t> tp((size_t)nt + 1, 0);
+        std::vector<int32_t> lo(nt), hi(nt);
+        size_t k = 0;
+        for (int t = 0; t < nt; ++t) {
+            lo[t] = pt_tile[t];
+            hi[t] = pt_tile[t + 1];
+            while (k < rows.size() && rows[k] < hi[t]) ++k;
+            tp[t + 1] = (int64_t)k;
+        }
+        PlanSpec s;
+        s.A = A;
+        s.rows = rows.data();
+        s.n_rows = (int64_t)rows.size();
+        s.tile_ptr = tp.data();
+        s.n_tiles = nt;
+        s.own_lo = lo.data();
+        s.own_hi = hi.data();
+        s.extract_diag = true;
+        s.need_self = true;
+        s.in_place = true;
+        s.mult_col = d.neumann_flag ? n : -1;
+        s.L = L;
+        err = build_plan(s, out);
+        if (err.empty() || err.rfind("tile-too-large", 0) != 0) return err;
+        std::vector<int32_t> split;  // halve every tile and retry
+        for (int t = 0; t < nt; ++t) {
+            split.push_back(pt_tile[t]);
+            const int mid = (pt_tile[t] + pt_tile[t + 1]) / 2;
+            if (mid > pt_tile[t] && mid < pt_tile[t + 1]) split.push_back(mid);
+        }
+        split.push_back(n);
+        pt_tile.swap(split);
+    }
+    return err;
+}
+
+std::string build_boundary_lists(const mmg_level_desc &d, BoundaryLists *out)
+{
+    const int n = d.n;
+    std::vector<int32_t> last_dir((size_t)n, -1), last_neu((size_t)n, -1);
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int b = 0; b < d.nb; ++b)
+        for (int k = d.bptr[b]; k < d.bptr[b + 1]; ++k) {
+            const int p = d.bpts[k];
+            if (p < 0 || p >= n) return "boundary point out of range";
+            if (d.btype[b] == 1) last_dir[p] = k;
+            if (d.btype[b] == 2) {
+                last_neu[p] = k;
+                if (!seen[p]) { seen[p] = 1; out->neu_rows.push_back(p); }
+            }
+        }
+    for (int p = 0; p < n; ++p) {
+        if (last_dir[p] >= 0) { out->dir_idx.push_back(p); out->dir_src.push_back(last_dir[p]); }
+        if (last_neu[p] >= 0) { out->neu_idx.push_back(p); out->neu_src.push_back(last_neu[p]); }
+    }
+    return std::string();
+}
+
+std::string check_multiplier(const mmg_level_desc &d)
+{
+    if (!d.neumann_flag) return std::string();
+    const int n = d.n;
+    for (int p = d.rowptr[n]; p < d.rowptr[n + 1]; ++p) {
+        const int c = d.col[p];
+        const bool expect = (c == n) || (c >= 0 && c < n && d.bcflags[c] != 2);
+        if (d.val[p] != 1.0 || !expect) return "multiplier row is not the reference's row of ones";
+    }
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) cnt += d.bcflags[i] != 2;
+    if (d.rowptr[n + 1] - d.rowptr[n] != cnt + 1) return "multiplier row does not cover every non-Neumann point";
+    return std::string();
+}
+
+void csc_to_csr(int rows, int cols, const int *colptr, const int *rowidx, const double *val,
+                std::vector<int> *rowptr, std::vector<int> *col, std::vector<double> *rval)
+{
+    const int nnz = colptr[cols];
+    rowptr->assign((size_t)rows + 1, 0);
+    for (int p = 0; p < nnz; ++p) (*rowptr)[rowidx[p] + 1]++;
+    for (int i = 0; i < rows; ++i) (*rowptr)[i + 1] += (*rowptr)[i];
+    col->resize(nnz);
+    rval->resize(nnz);
+    std::vector<int> cur(rowptr->begin(), rowptr->end() - 1);
+    // columns ascending inside a row == Eigen's column-major accumulation order
+    for (int j = 0; j < cols; ++j)
+        for (int p = colptr[j]; p < colptr[j + 1]; ++p) {
+            const int q = cur[rowidx[p]]++;
+            (*col)[q] = j;
+            (*rval)[q] = val[p];
+        }
+}
+
+}  // namespace mmg

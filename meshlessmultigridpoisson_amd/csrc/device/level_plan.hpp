@@ -1,0 +1,36 @@
+// level_plan.hpp -- host-only helpers that turn the C-ABI's inputs into plans.
+// Shared by capi.cpp (product) and tests/support/plan_emulate.cpp (CPU check of
+// the packed layout; test infrastructure only).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/mmgp.h"
+#include "plan.hpp"
+
+namespace mmg {
+
+// Non-in-place or in-place gather plan over `rows` with automatic tile size
+// (halves tile_rows until every tile fits the LDS slot budget).
+std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows,
+                                   bool diag, bool self, bool in_place, int mult_col, Plan *out);
+
+// Plan A of a level: interior rows (bcflags == 0) in storage order, own range of
+// a tile == its points.  Tile boundaries come from desc.tile_ptr or tile_size.
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out);
+
+// Boundary bookkeeping of a level (deduplicated, last writer wins).
+struct BoundaryLists {
+    std::vector<int32_t> dir_idx, dir_src;  // Dirichlet points and the position of their value in bvals
+    std::vector<int32_t> neu_idx, neu_src;  // Neumann points, same
+    std::vector<int32_t> neu_rows;          // bound_eval_neumann order (first occurrence)
+};
+std::string build_boundary_lists(const mmg_level_desc &d, BoundaryLists *out);
+
+// Checks the reference's multiplier row/column structure (grid.cpp:566-576).
+std::string check_multiplier(const mmg_level_desc &d);
+
+void csc_to_csr(int rows, int cols, const int *colptr, const int *rowidx, const double *val,
+                std::vector<int> *rowptr, std::vector<int> *col, std::vector<double> *rval);
+
+}  // namespace mmg

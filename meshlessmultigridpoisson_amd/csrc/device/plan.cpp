@@ -1,0 +1,334 @@
+// plan.cpp -- host-side builder of the packed tile plan (see plan.hpp).
+//
+// Exactness argument.  The reference relaxes rows one after the other in storage
+// order (grid.cpp:117-143).  Two rows i<j "couple" when a_ij != 0 or a_ji != 0
+// (stored explicit zeros excluded).  Any schedule that runs coupled rows in
+// their sequential order produces bit-for-bit the sequential iterates (up to the
+// association order inside one row's dot product).  The builder therefore
+//   * gives every row of a tile a level = 1 + max level of its coupled earlier
+//     rows of the same tile, and emits groups level by level;
+//   * gives every tile a phase = 1 + max phase of its coupled earlier tiles, and
+//     launches phases one after the other.
+// Nothing here assumes a particular point ordering: a multicolour ordering
+// (host `Grid::mc_order_points`) yields few levels/phases, an RCM ordering many;
+// both are exact.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace mmg {
+
+std::vector<int64_t> uniform_tile_ptr(int64_t n_rows, int rows_per_tile)
+{
+    std::vector<int64_t> tp;
+    if (rows_per_tile < 1) rows_per_tile = 1;
+    for (int64_t r = 0; r < n_rows; r += rows_per_tile) tp.push_back(r);
+    tp.push_back(n_rows);
+    if (tp.size() == 1) tp.push_back(n_rows);
+    return tp;
+}
+
+namespace {
+
+struct TileBuild {
+    std::vector<uint8_t> blob;
+    std::vector<int32_t> halo;
+    std::vector<uint32_t> ghead;
+    std::vector<int32_t> nbr;  // coupled tiles (unsorted, may repeat)
+    uint32_t n_own = 0, row0 = 0;
+    long long nnz = 0;
+    std::string err;
+};
+
+struct Ctx {
+    const PlanSpec *s;
+    std::vector<int32_t> rowpos;     // input index -> sequence position, -1 if not a row
+    std::vector<int32_t> tile_of;    // sequence position -> tile
+};
+
+struct Entry { uint16_t slot; double val; };
+
+void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &tb)
+{
+    const PlanSpec &s = *c.s;
+    const CsrView &A = s.A;
+    const int L = s.L, G = 64 / L;
+    const int64_t r0 = s.tile_ptr[t], r1 = s.tile_ptr[t + 1];
+    const int m = (int)(r1 - r0);
+    const int32_t lo = s.own_lo ? s.own_lo[t] : 0;
+    const int32_t hi = s.own_lo ? s.own_hi[t] : 0;
+    const uint32_t n_own = (uint32_t)(hi - lo);
+    tb.n_own = n_own;
+    tb.row0 = (uint32_t)lo;
+
+    // ---- pass 1: discover the halo --------------------------------------
+    auto touch = [&](int32_t col) {
+        if (col >= lo && col < hi) return;
+        if (slot_of[col] < 0) { slot_of[col] = 0; tb.halo.push_back(col); }
+    };
+    for (int64_t k = r0; k < r1; ++k) {
+        const int32_t gid = s.rows[k];
+        bool has_diag = false;
+        for (int p = A.rowptr[gid]; p < A.rowptr[gid + 1]; ++p) {
+            const int32_t col = A.col[p];
+            const double v = A.val[p];
+            if (col == s.mult_col) {
+                if (v != 1.0) tb.err = "multiplier column entry != 1.0";
+                continue;
+            }
+            if (s.extract_diag && col == gid) { has_diag = true; continue; }
+            if (v == 0.0) continue;  // explicit zero kept by setFromTriplets
+            touch(col);
+        }
+        if ((s.extract_diag && has_diag) || s.need_self) touch(gid);
+        (void)has_diag;
+    }
+    std::sort(tb.halo.begin(), tb.halo.end());
+    for (size_t i = 0; i < tb.halo.size(); ++i) slot_of[tb.halo[i]] = (int32_t)(n_own + i);
+    const size_t n_slots = (size_t)n_own + tb.halo.size() + 1;
+    auto cleanup = [&]() { for (int32_t h : tb.halo) slot_of[h] = -1; };
+    if (n_slots > (size_t)kMaxSlots) {
+        tb.err = "tile-too-large: " + std::to_string(n_slots) + " LDS slots";
+        cleanup();
+        return;
+    }
+    const uint16_t zero_slot = (uint16_t)(n_slots - 1);
+    auto slot = [&](int32_t col) -> uint16_t {
+        if (col >= lo && col < hi) return (uint16_t)(col - lo);
+        return (uint16_t)slot_of[col];
+    };
+
+    // ---- pass 2: per-row entry lists, dependencies ------------------------
+    std::vector<std::vector<Entry>> ent(m);
+    std::vector<double> diag(m, 0.0);
+    std::vector<RowMeta> meta(m);
+    std::vector<std::vector<int32_t>> lower;  // coupled earlier rows of the tile
+    if (s.in_place) lower.resize(m);
+    for (int k = 0; k < m; ++k) {
+        const int32_t gid = s.rows[r0 + k];
+        uint16_t flags = 0;
+        bool has_diag = false;
+        for (int p = A.rowptr[gid]; p < A.rowptr[gid + 1]; ++p) {
+            const int32_t col = A.col[p];
+            const double v = A.val[p];
+            if (col == s.mult_col) { flags |= 1; continue; }
+            if (s.extract_diag && col == gid) { diag[k] = v; has_diag = true; continue; }
+            if (v == 0.0) continue;
+            ent[k].push_back({slot(col), v});
+            if (s.in_place && col != gid) {
+                const int32_t pos = c.rowpos[col];
+                if (pos >= 0) {
+                    const int32_t tt = c.tile_of[pos];
+                    if (tt == t) {
+                        const int kk = (int)(pos - r0);
+                        if (kk < k) lower[k].push_back(kk); else lower[kk].push_back(k);
+                    } else {
+                        tb.nbr.push_back(tt);
+                    }
+                }
+            }
+        }
+        uint16_t self = kNoSlot;
+        if (gid >= lo && gid < hi) self = (uint16_t)(gid - lo);
+        else if ((s.extract_diag && has_diag) || s.need_self) self = (uint16_t)slot_of[gid];
+        meta[k] = RowMeta{(uint32_t)gid, self, flags};
+        tb.nnz += (long long)ent[k].size();
+    }
+    cleanup();
+
+    // ---- levels ------------------------------------------------------------
+    std::vector<int32_t> level(m, 0);
+    int n_levels = 1;
+    if (s.in_place) {
+        for (int k = 0; k < m; ++k) {
+            int lv = 0;
+            for (int32_t j : lower[k]) lv = std::max(lv, level[j] + 1);
+            level[k] = lv;
+            n_levels = std::max(n_levels, lv + 1);
+        }
+    }
+    std::vector<std::vector<int32_t>> by_level(n_levels);
+    for (int k = 0; k < m; ++k) by_level[level[k]].push_back(k);
+
+    // ---- pack groups ---------------------------------------------------------
+    for (int lv = 0; lv < n_levels; ++lv) {
+        const auto &rows = by_level[lv];
+        for (size_t g0 = 0; g0 < rows.size(); g0 += G) {
+            const int g = (int)std::min<size_t>(G, rows.size() - g0);
+            int plen = 0;
+            for (int i = 0; i < g; ++i)
+                plen = std::max(plen, (int)((ent[rows[g0 + i]].size() + L - 1) / L));
+            const size_t W = (size_t)g * L;
+            const size_t plen4 = ((size_t)plen + 3) / 4;
+            const size_t base = tb.blob.size();
+            const size_t vals_off = base + (size_t)16 * g;
+            const size_t slots_off = vals_off + align16((size_t)plen * W * 8);
+            tb.blob.resize(base + group_bytes(L, g, plen), 0);
+            uint8_t *B = tb.blob.data();
+            for (int i = 0; i < g; ++i) {
+                const int k = rows[g0 + i];
+                std::memcpy(B + base + (size_t)8 * i, &meta[k], 8);
+                std::memcpy(B + base + (size_t)8 * g + (size_t)8 * i, &diag[k], 8);
+            }
+            // fill everything with padding first
+            for (size_t q = 0; q < plen4 * 4; ++q)
+                for (size_t lane = 0; lane < W; ++lane) {
+                    const size_t si = ((q / 4) * W + lane) * 4 + (q % 4);
+                    std::memcpy(B + slots_off + si * 2, &zero_slot, 2);
+                }
+            for (int i = 0; i < g; ++i) {
+                const auto &e = ent[rows[g0 + i]];
+                for (size_t x = 0; x < e.size(); ++x) {
+                    const size_t q = x / L, sub = x % L;
+                    const size_t lane = (size_t)i * L + sub;
+                    std::memcpy(B + vals_off + (q * W + lane) * 8, &e[x].val, 8);
+                    const size_t si = ((q / 4) * W + lane) * 4 + (q % 4);
+                    std::memcpy(B + slots_off + si * 2, &e[x].slot, 2);
+                }
+            }
+            tb.ghead.push_back((uint32_t)g | ((uint32_t)plen << 8));
+        }
+    }
+}
+
+}  // namespace
+
+std::string build_plan(const PlanSpec &s, Plan *out)
+{
+    if (!out) return "null plan";
+    const int L = s.L;
+    if (!(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32 || L == 64))
+        return "lanes_per_row must be a power of two <= 64";
+    if (s.n_tiles < 1 || !s.tile_ptr || (!s.rows && s.n_rows > 0)) return "bad plan spec";
+    if (s.tile_ptr[0] != 0 || s.tile_ptr[s.n_tiles] != s.n_rows) return "tile_ptr does not cover rows";
+    const CsrView &A = s.A;
+    const int n_in = A.cols;
+
+    Ctx c;
+    c.s = &s;
+    if (s.in_place) {
+        c.rowpos.assign(n_in, -1);
+        c.tile_of.resize((size_t)s.n_rows);
+        for (int64_t k = 0; k < s.n_rows; ++k) {
+            const int32_t r = s.rows[k];
+            if (r < 0 || r >= n_in) return "row id outside the input vector";
+            if (c.rowpos[r] >= 0) return "row listed twice";
+            c.rowpos[r] = (int32_t)k;
+        }
+        for (int t = 0; t < s.n_tiles; ++t)
+            for (int64_t k = s.tile_ptr[t]; k < s.tile_ptr[t + 1]; ++k) c.tile_of[k] = t;
+    }
+    for (int64_t k = 0; k < s.n_rows; ++k)
+        if (s.rows[k] < 0 || s.rows[k] >= A.rows) return "row id outside the matrix";
+
+    std::vector<TileBuild> tb(s.n_tiles);
+    int nt = s.n_threads > 0 ? s.n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    nt = std::min(nt, s.n_tiles);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        std::vector<int32_t> slot_of((size_t)n_in, -1);
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= s.n_tiles) break;
+            build_tile(c, t, slot_of, tb[t]);
+        }
+    };
+    if (nt == 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; ++i) th.emplace_back(worker);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < s.n_tiles; ++t)
+        if (!tb[t].err.empty()) return tb[t].err;
+
+    // ---- assemble ------------------------------------------------------------
+    Plan &P = *out;
+    P = Plan();
+    P.L = L;
+    P.n_tiles = s.n_tiles;
+    P.tiles.resize(s.n_tiles);
+    size_t stream_sz = 0, halo_sz = 0, gh_sz = 0;
+    for (int t = 0; t < s.n_tiles; ++t) {
+        TileDesc &d = P.tiles[t];
+        std::memset(&d, 0, sizeof(d));
+        d.stream_off = stream_sz;
+        d.halo_off = halo_sz;
+        d.ghead_off = (uint32_t)gh_sz;
+        d.row0 = tb[t].row0;
+        d.n_own = tb[t].n_own;
+        d.n_halo = (uint32_t)tb[t].halo.size();
+        d.n_groups = (uint32_t)tb[t].ghead.size();
+        d.n_rows = (uint32_t)(s.tile_ptr[t + 1] - s.tile_ptr[t]);
+        stream_sz += tb[t].blob.size();
+        halo_sz += tb[t].halo.size();
+        gh_sz += tb[t].ghead.size();
+        P.max_slots = std::max<int>(P.max_slots, (int)(d.n_own + d.n_halo + 1));
+        P.max_groups = std::max<int>(P.max_groups, (int)d.n_groups);
+        P.n_nnz += tb[t].nnz;
+    }
+    P.n_rows = s.n_rows;
+    P.n_groups = (long long)gh_sz;
+    P.stream.resize(stream_sz + 64);  // tail slack: kernels may prefetch past the end
+    P.halo.resize(halo_sz);
+    P.ghead.resize(gh_sz);
+    {
+        std::atomic<int> nx{0};
+        auto copier = [&]() {
+            for (;;) {
+                const int t = nx.fetch_add(1);
+                if (t >= s.n_tiles) break;
+                const TileDesc &d = P.tiles[t];
+                if (!tb[t].blob.empty()) std::memcpy(P.stream.data() + d.stream_off, tb[t].blob.data(), tb[t].blob.size());
+                if (!tb[t].halo.empty()) std::memcpy(P.halo.data() + d.halo_off, tb[t].halo.data(), tb[t].halo.size() * 4);
+                if (!tb[t].ghead.empty()) std::memcpy(P.ghead.data() + d.ghead_off, tb[t].ghead.data(), tb[t].ghead.size() * 4);
+                std::vector<uint8_t>().swap(tb[t].blob);
+            }
+        };
+        if (nt == 1) copier();
+        else {
+            std::vector<std::thread> th;
+            for (int i = 0; i < nt; ++i) th.emplace_back(copier);
+            for (auto &x : th) x.join();
+        }
+    }
+
+    // ---- phases --------------------------------------------------------------
+    std::vector<int32_t> phase(s.n_tiles, 0);
+    int n_phases = 1;
+    if (s.in_place) {
+        // symmetrise: edge (a,b) stored at max(a,b) as "depends on min(a,b)"
+        std::vector<std::vector<int32_t>> dep(s.n_tiles);
+        for (int t = 0; t < s.n_tiles; ++t) {
+            auto &nb = tb[t].nbr;
+            std::sort(nb.begin(), nb.end());
+            nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+            for (int32_t u : nb) {
+                if (u < t) dep[t].push_back(u);
+                else if (u > t) dep[u].push_back(t);
+            }
+        }
+        for (int t = 0; t < s.n_tiles; ++t) {
+            int ph = 0;
+            for (int32_t u : dep[t]) ph = std::max(ph, phase[u] + 1);
+            phase[t] = ph;
+            n_phases = std::max(n_phases, ph + 1);
+        }
+    }
+    P.phase_ptr.assign(n_phases + 1, 0);
+    for (int t = 0; t < s.n_tiles; ++t) P.phase_ptr[phase[t] + 1]++;
+    for (int p = 0; p < n_phases; ++p) P.phase_ptr[p + 1] += P.phase_ptr[p];
+    P.phase_tiles.resize(s.n_tiles);
+    {
+        std::vector<int32_t> cur(P.phase_ptr.begin(), P.phase_ptr.end() - 1);
+        for (int t = 0; t < s.n_tiles; ++t) P.phase_tiles[cur[phase[t]]++] = t;
+    }
+    return std::string();
+}
+
+}  // namespace mmg

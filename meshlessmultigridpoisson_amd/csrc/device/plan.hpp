@@ -8,20 +8,21 @@
 //   tiles   : a contiguous chunk of the row sequence  -> one wavefront each;
 //             every input value the tile touches is staged ONCE in LDS
 //             (own range: coalesced; the rest: gathered through `halo`)
-//   groups  : 64/L rows relaxed together by one wavefront, L lanes per row;
-//             groups of a tile are ordered by dependency level, so executing
-//             them in order inside one wavefront reproduces the sequential
-//             (Gauss-Seidel) order of the reference exactly
+//   groups  : up to 64/L rows relaxed together by one wavefront, L lanes per
+//             row; the groups of a tile are ordered by dependency level, so
+//             executing them in order inside one wavefront reproduces the
+//             sequential (Gauss-Seidel) order of the reference exactly
 //
-// Per group the stream holds, 16-byte aligned and in this order:
-//   RowMeta  meta[G]            (8 B each)
-//   double   diag[G]
-//   double   val [plen*64]      val [q*64 + lane] : entry q of lane's row share
-//   uint16   slot[plen4*64*4]   slot[((q/4)*64 + lane)*4 + q%4] : LDS slot of the
-//                               column (tile-local, 16 bit -- 10 B per stored
-//                               entry instead of CSR's 12 B)
-// with G = 64/L, lane = row_in_group*L + sub, plen4 = ceil(plen/4).
-// Padding entries carry val = 0 and point at the tile's zero slot.
+// Per group (g rows, W = g*L active lanes, plen entries per lane) the stream
+// holds, each section padded to 16 bytes, in this order:
+//   RowMeta  meta[g]            (8 B each)
+//   double   diag[g]
+//   double   val [plen*W]       val [q*W + lane]
+//   uint16   slot[plen4*W*4]    slot[((q/4)*W + lane)*4 + q%4]  (plen4=ceil(plen/4))
+// lane = row_in_group*L + sub; entry e of a row sits at q = e/L, sub = e%L.
+// `slot` is the tile-local LDS slot of the entry's column (16 bit: a stored
+// entry costs 10 B instead of CSR's 12 B).  Padding entries carry val = 0 and
+// point at the tile's zero slot.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -51,20 +52,30 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout");
 
 struct RowMeta {
     uint32_t gid;          // output index of the row
-    uint16_t self;         // LDS slot holding in[gid] (0xFFFF: not staged)
+    uint16_t self;         // LDS slot holding in[gid] (kNoSlot: not staged)
     uint16_t flags;        // bit0: row has the multiplier column (coefficient 1)
 };
 static_assert(sizeof(RowMeta) == 8, "RowMeta layout");
 
 constexpr uint16_t kNoSlot = 0xFFFF;
-constexpr int kMaxSlots = 7936;  // (slots+1)*8 B + group heads must fit 64 KiB LDS
+constexpr int kMaxSlots = 7936;  // slots*8 B + group heads must fit 64 KiB of LDS
+
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// byte size of one packed group
+inline size_t group_bytes(int L, int g, int plen)
+{
+    const size_t W = (size_t)g * L;
+    const size_t plen4 = ((size_t)plen + 3) / 4;
+    return (size_t)16 * g + align16((size_t)plen * W * 8) + align16(plen4 * W * 8);
+}
 
 struct Plan {
     int L = 4;                         // lanes per row
     int n_tiles = 0;
     std::vector<TileDesc> tiles;
     std::vector<int32_t> halo;         // input indices staged after the own range
-    std::vector<uint32_t> ghead;       // per group: n_rows | plen << 8
+    std::vector<uint32_t> ghead;       // per group: g | plen << 8
     std::vector<uint8_t> stream;       // packed groups
     std::vector<int32_t> phase_ptr;    // n_phases + 1
     std::vector<int32_t> phase_tiles;  // tiles ordered by phase
@@ -86,8 +97,8 @@ struct PlanSpec {
     // Tile boundaries as offsets into rows[] (n_tiles+1 entries).
     const int64_t *tile_ptr = nullptr;
     int n_tiles = 0;
-    // Optional per-tile own range of the INPUT vector staged coalesced
-    // (own_lo[t], own_hi[t]); nullptr = everything goes through the halo list.
+    // Optional per-tile own range [own_lo[t], own_hi[t]) of the INPUT vector,
+    // staged coalesced; nullptr = everything goes through the halo list.
     const int32_t *own_lo = nullptr;
     const int32_t *own_hi = nullptr;
     bool extract_diag = false;  // pull a_rr out of the sum (SOR / bound_eval / residual)
@@ -99,16 +110,10 @@ struct PlanSpec {
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).
+// A reason starting with "tile-too-large" asks the caller to retry with
+// smaller tiles.
 std::string build_plan(const PlanSpec &spec, Plan *out);
 
-// Helpers shared with capi.cpp
 std::vector<int64_t> uniform_tile_ptr(int64_t n_rows, int rows_per_tile);
-
-inline size_t group_bytes(int L, int plen)
-{
-    const int G = 64 / L;
-    const int plen4 = (plen + 3) / 4;
-    return (size_t)16 * G + (size_t)plen * 512 + (size_t)plen4 * 512;
-}
 
 }  // namespace mmg

@@ -1,0 +1,161 @@
+"""Shared test helpers: fixture loading, oracle/device/emulator construction."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SUPPORT = os.path.join(ROOT, "tests", "support")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def ensure_built():
+    from oracle import oracle_c
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libmmg_oracle.so")):
+        oracle_c.build()
+    emu = os.path.join(SUPPORT, "libplan_emulate.so")
+    srcs = [os.path.join(SUPPORT, "plan_emulate.cpp"),
+            os.path.join(ROOT, "meshlessmultigridpoisson_amd", "csrc", "device", "plan.cpp"),
+            os.path.join(ROOT, "meshlessmultigridpoisson_amd", "csrc", "device", "level_plan.cpp")]
+    if not os.path.exists(emu) or any(os.path.getmtime(s) > os.path.getmtime(emu) for s in srcs):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", emu] + srcs, check=True)
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = {k: z[k] for k in z.files}
+    case["nlevels"] = int(case["nlevels"])
+    return case
+
+
+def level_arrays(case, i):
+    p = f"L{i}_"
+    n, a_size, neumann, iters = [int(v) for v in case[p + "meta"]]
+    return dict(n=n, rowptr=case[p + "rowptr"], col=case[p + "col"], val=case[p + "val"],
+                bcflags=case[p + "bcflags"], neumann=neumann, omega=float(case[p + "omega"]), iters=iters,
+                btype=case[p + "btype"], bptr=case[p + "bptr"], bpts=case[p + "bpts"], bvals=case[p + "bvals"],
+                x0=case[p + "x0"], b0=case[p + "b0"], a_size=a_size)
+
+
+def oracle_level(la):
+    from oracle import oracle_c as oc
+    return oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"], la["neumann"],
+                    la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"])
+
+
+def oracle_multigrid(case):
+    from oracle import oracle_c as oc
+    nl = case["nlevels"]
+    levels = [oracle_level(level_arrays(case, i)) for i in range(nl)]
+    R, P = [None] * nl, [None] * nl
+    for i in range(nl):
+        if f"R{i}_shape" in case:
+            R[i] = oc.Transfer(*case[f"R{i}_shape"], case[f"R{i}_colptr"], case[f"R{i}_rowidx"], case[f"R{i}_val"])
+        if f"P{i}_shape" in case:
+            P[i] = oc.Transfer(*case[f"P{i}_shape"], case[f"P{i}_colptr"], case[f"P{i}_rowidx"], case[f"P{i}_val"])
+    return oc.Multigrid(levels, R, P, frac_step=bool(case["frac_step"]))
+
+
+def device_level(la, **kw):
+    from meshlessmultigridpoisson_amd import _capi
+    return _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], la["neumann"], la["omega"],
+                       la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"], x=la["x0"], b=la["b0"], **kw)
+
+
+def device_hierarchy(case, frac_step=None, **kw):
+    from meshlessmultigridpoisson_amd import _capi
+    nl = case["nlevels"]
+    levels = [device_level(level_arrays(case, i), **kw) for i in range(nl)]
+    R, P = [None] * nl, [None] * nl
+    for i in range(nl):
+        if f"R{i}_shape" in case:
+            R[i] = _capi.Transfer(*case[f"R{i}_shape"], case[f"R{i}_colptr"], case[f"R{i}_rowidx"], case[f"R{i}_val"])
+        if f"P{i}_shape" in case:
+            P[i] = _capi.Transfer(*case[f"P{i}_shape"], case[f"P{i}_colptr"], case[f"P{i}_rowidx"], case[f"P{i}_val"])
+    fs = bool(case["frac_step"]) if frac_step is None else frac_step
+    return _capi.Hierarchy(levels, R, P, frac_step=fs)
+
+
+# ---- CPU interpreter of the packed plan (tests/support/plan_emulate.cpp) ------------
+_emu = None
+
+
+def emu_lib():
+    global _emu
+    if _emu is None:
+        ensure_built()
+        L = C.CDLL(os.path.join(SUPPORT, "libplan_emulate.so"))
+        L.emu_level_create.restype = C.c_void_p
+        L.emu_last_error.restype = C.c_char_p
+        L.emu_level_destroy.argtypes = [C.c_void_p]
+        L.emu_level_info.argtypes = [C.c_void_p, _ip]
+        L.emu_level_sweeps.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int]
+        L.emu_level_bound_eval.argtypes = [C.c_void_p, _dp, _dp]
+        L.emu_level_residual.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.emu_level_residual.restype = C.c_double
+        L.emu_level_stream_bytes.argtypes = [C.c_void_p]
+        L.emu_level_stream_bytes.restype = C.c_longlong
+        L.emu_level_nnz.argtypes = [C.c_void_p]
+        L.emu_level_nnz.restype = C.c_longlong
+        L.emu_transfer_apply.argtypes = [C.c_int, C.c_int, _ip, _ip, _dp, _dp, _dp, C.c_int, C.c_int]
+        _emu = L
+    return _emu
+
+
+class EmuLevel:
+    def __init__(self, la, tile_ptr=None, tile_size=0, lanes_per_row=0):
+        from meshlessmultigridpoisson_amd import _capi
+        d, self._keep = _capi.make_desc(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], la["neumann"],
+                                        la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"],
+                                        tile_ptr, tile_size, lanes_per_row)
+        self.L = emu_lib()
+        self.h = self.L.emu_level_create(C.byref(d))
+        if not self.h:
+            raise RuntimeError(self.L.emu_last_error().decode())
+        self.x = np.array(la["x0"], dtype=np.float64)
+        self.b = np.array(la["b0"], dtype=np.float64)
+        self.omega = la["omega"]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.emu_level_destroy(self.h)
+
+    def info(self):
+        out = np.zeros(6, dtype=np.int32)
+        self.L.emu_level_info(self.h, out.ctypes.data_as(_ip))
+        return dict(zip(["n_tiles", "n_phases", "n_groups", "max_slots", "b_tiles", "b_phases"], out.tolist()))
+
+    def sweeps(self, k):
+        self.L.emu_level_sweeps(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp), self.omega, int(k))
+
+    def bound_eval(self):
+        self.L.emu_level_bound_eval(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp))
+
+    def residual(self):
+        r = np.zeros_like(self.x)
+        nrm = self.L.emu_level_residual(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp),
+                                        r.ctypes.data_as(_dp))
+        return r, nrm
+
+
+def emu_transfer_apply(shape, colptr, rowidx, val, x, add_to=None, L=4):
+    rows, cols = int(shape[0]), int(shape[1])
+    colptr = np.ascontiguousarray(colptr, dtype=np.int32)
+    rowidx = np.ascontiguousarray(rowidx, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(rows) if add_to is None else np.array(add_to, dtype=np.float64)
+    rc = emu_lib().emu_transfer_apply(rows, cols, colptr.ctypes.data_as(_ip), rowidx.ctypes.data_as(_ip),
+                                      val.ctypes.data_as(_dp), x.ctypes.data_as(_dp), y.ctypes.data_as(_dp),
+                                      int(add_to is not None), int(L))
+    assert rc == 0, emu_lib().emu_last_error()
+    return y
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

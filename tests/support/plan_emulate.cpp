@@ -1,0 +1,221 @@
+// plan_emulate.cpp -- TEST INFRASTRUCTURE ONLY (never linked into libmmgp.so).
+//
+// CPU interpreter of the packed tile plan (csrc/device/plan.hpp): walks the same
+// bytes the gfx950 kernels stream, with the same semantics, so that the layout,
+// the level/phase schedule and the multiplier/diagonal handling can be checked
+// against the oracle in the GPU-less container.  To make schedule errors
+// visible it is deliberately adversarial: all tiles of a phase read a snapshot
+// taken at the start of the phase (as if they ran fully concurrently), and all
+// rows of a group read LDS before any of them writes.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mmgp.h"
+#include "../../meshlessmultigridpoisson_amd/csrc/device/level_plan.hpp"
+#include "../../meshlessmultigridpoisson_amd/csrc/device/plan.hpp"
+
+using namespace mmg;
+
+namespace {
+
+enum { M_SOR, M_BOUND, M_RESID, M_SET, M_ADD };
+
+struct Emu {
+    int n = 0, a_size = 0, neumann = 0;
+    Plan A, B;
+    BoundaryLists bl;
+    std::vector<uint8_t> flags;
+};
+
+thread_local std::string g_err;
+
+void run_tile(const Plan &P, int tile, int mode, const double *in, double *out, const double *b, double omega,
+              double lam, double *abs_acc)
+{
+    const TileDesc &td = P.tiles[tile];
+    const int L = P.L;
+    const uint32_t n_slots = td.n_own + td.n_halo + 1;
+    std::vector<double> xs(n_slots);
+    for (uint32_t i = 0; i < td.n_own; ++i) xs[i] = in[td.row0 + i];
+    for (uint32_t i = 0; i < td.n_halo; ++i) xs[td.n_own + i] = in[P.halo[td.halo_off + i]];
+    xs[n_slots - 1] = 0.0;
+    const uint8_t *p = P.stream.data() + td.stream_off;
+    for (uint32_t g = 0; g < td.n_groups; ++g) {
+        const uint32_t h = P.ghead[td.ghead_off + g];
+        const int nr = (int)(h & 0xffu), plen = (int)(h >> 8), W = nr * L;
+        const RowMeta *meta = reinterpret_cast<const RowMeta *>(p);
+        const double *diag = reinterpret_cast<const double *>(p + (size_t)8 * nr);
+        const double *vals = reinterpret_cast<const double *>(p + (size_t)16 * nr);
+        const size_t vbytes = align16((size_t)plen * W * 8);
+        const uint16_t *sl = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(vals) + vbytes);
+        const int plen4 = (plen + 3) / 4;
+        std::vector<double> acc(nr, 0.0);
+        for (int r = 0; r < nr; ++r) {
+            double lane_acc[64] = {0};
+            for (int sub = 0; sub < L; ++sub) {
+                const int lane = r * L + sub;
+                for (int q = 0; q < plen; ++q) {
+                    const uint16_t s = sl[(((size_t)(q / 4)) * W + lane) * 4 + (q % 4)];
+                    lane_acc[sub] = std::fma(vals[(size_t)q * W + lane], xs[s], lane_acc[sub]);
+                }
+            }
+            for (int m = L >> 1; m >= 1; m >>= 1)
+                for (int sub = 0; sub < m; ++sub) lane_acc[sub] += lane_acc[sub + m];
+            acc[r] = lane_acc[0];
+        }
+        for (int r = 0; r < nr; ++r) {
+            const RowMeta m = meta[r];
+            const double d = diag[r];
+            if (mode == M_SOR) {
+                double xi = b[m.gid] - acc[r];
+                if (m.flags & 1) xi -= lam;
+                xi *= omega / d;
+                xi += (1.0 - omega) * xs[m.self];
+                xs[m.self] = xi;
+            } else if (mode == M_BOUND) {
+                const double xi = (b[m.gid] - acc[r]) / d;
+                out[m.gid] = xi;
+                if (m.self != kNoSlot) xs[m.self] = xi;
+            } else if (mode == M_RESID) {
+                double rr = b[m.gid] - (acc[r] + d * xs[m.self]);
+                if (m.flags & 1) rr -= lam;
+                out[m.gid] = rr;
+                if (abs_acc) *abs_acc += std::fabs(rr);
+            } else if (mode == M_SET) {
+                out[m.gid] = acc[r];
+            } else {
+                out[m.gid] += acc[r];
+            }
+        }
+        p += group_bytes(L, nr, plen);
+        (void)plen4;
+    }
+    if (mode == M_SOR)
+        for (uint32_t i = 0; i < td.n_own; ++i) out[td.row0 + i] = xs[i];
+}
+
+void run_plan(const Plan &P, int mode, double *x_inout, const double *in_other, double *out_other, const double *b,
+              double omega, double lam, size_t in_len, double *abs_acc)
+{
+    // in-place modes (SOR/BOUND): per-phase snapshot of x
+    const bool in_place = (mode == M_SOR || mode == M_BOUND);
+    for (int ph = 0; ph < P.n_phases(); ++ph) {
+        std::vector<double> snap;
+        const double *in = in_other;
+        double *out = out_other;
+        if (in_place) {
+            snap.assign(x_inout, x_inout + in_len);
+            in = snap.data();
+            out = x_inout;
+        }
+        for (int k = P.phase_ptr[ph]; k < P.phase_ptr[ph + 1]; ++k)
+            run_tile(P, P.phase_tiles[k], mode, in, out, b, omega, lam, abs_acc);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *emu_last_error() { return g_err.c_str(); }
+
+void *emu_level_create(const mmg_level_desc *d)
+{
+    auto e = std::make_unique<Emu>();
+    e->n = d->n;
+    e->a_size = d->a_size;
+    e->neumann = d->neumann_flag ? 1 : 0;
+    const int L = d->lanes_per_row > 0 ? d->lanes_per_row : 4;
+    std::string err = check_multiplier(*d);
+    if (err.empty()) err = build_boundary_lists(*d, &e->bl);
+    if (err.empty()) err = build_level_plan(*d, L, &e->A);
+    if (err.empty() && !e->bl.neu_rows.empty()) {
+        CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
+        err = build_gather_plan_host(A, e->bl.neu_rows, L, 64, true, true, true, -1, &e->B);
+    }
+    if (!err.empty()) { g_err = err; return nullptr; }
+    e->flags.assign(d->bcflags, d->bcflags + d->n);
+    return e.release();
+}
+
+void emu_level_destroy(void *h) { delete static_cast<Emu *>(h); }
+
+void emu_level_info(void *h, int *out6)
+{
+    Emu *e = static_cast<Emu *>(h);
+    out6[0] = e->A.n_tiles;
+    out6[1] = e->A.n_phases();
+    out6[2] = (int)e->A.n_groups;
+    out6[3] = e->A.max_slots;
+    out6[4] = e->B.n_tiles;
+    out6[5] = e->B.n_rows ? e->B.n_phases() : 0;
+}
+
+long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
+long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
+
+void emu_level_bound_eval(void *h, double *x, const double *b)
+{
+    Emu *e = static_cast<Emu *>(h);
+    if (e->B.n_rows) run_plan(e->B, M_BOUND, x, nullptr, nullptr, b, 0.0, 0.0, (size_t)e->a_size, nullptr);
+}
+
+void emu_level_sweeps(void *h, double *x, const double *b, double omega, int nsweeps)
+{
+    Emu *e = static_cast<Emu *>(h);
+    for (int it = 0; it < nsweeps; ++it) {
+        const double lam = e->neumann ? x[e->n] : 0.0;
+        run_plan(e->A, M_SOR, x, nullptr, nullptr, b, omega, lam, (size_t)e->a_size, nullptr);
+        if (e->neumann) {
+            double S = 0.0;
+            for (int i = 0; i < e->n; ++i)
+                if (e->flags[i] != 2) S += x[i];
+            double xi = b[e->n] - S;
+            xi *= omega / 1.0;
+            xi += (1.0 - omega) * x[e->n];
+            x[e->n] = xi;
+        }
+        emu_level_bound_eval(h, x, b);
+    }
+}
+
+double emu_level_residual(void *h, const double *x, const double *b, double *r)
+{
+    Emu *e = static_cast<Emu *>(h);
+    for (int i = 0; i < e->a_size; ++i) r[i] = 0.0;
+    double nrm = 0.0;
+    const double lam = e->neumann ? x[e->n] : 0.0;
+    run_plan(e->A, M_RESID, nullptr, x, r, b, 0.0, lam, 0, &nrm);
+    if (e->B.n_rows) run_plan(e->B, M_RESID, nullptr, x, r, b, 0.0, 0.0, 0, &nrm);
+    for (int32_t i : e->bl.dir_idx) r[i] = 0.0;
+    if (e->neumann) {
+        double S = 0.0;
+        for (int i = 0; i < e->n; ++i)
+            if (e->flags[i] != 2) S += x[i];
+        r[e->n] = b[e->n] - (S + x[e->n]);
+        nrm += std::fabs(r[e->n]);
+    }
+    return nrm;
+}
+
+// y (=|+=) M x for a transfer given in the reference's column-major storage
+int emu_transfer_apply(int rows, int cols, const int *colptr, const int *rowidx, const double *val, const double *x,
+                       double *y, int add, int L)
+{
+    std::vector<int> rp, ci;
+    std::vector<double> rv;
+    csc_to_csr(rows, cols, colptr, rowidx, val, &rp, &ci, &rv);
+    std::vector<int32_t> all((size_t)rows);
+    for (int i = 0; i < rows; ++i) all[i] = i;
+    CsrView A{rows, cols, rp.data(), ci.data(), rv.data()};
+    Plan P;
+    const std::string err = build_gather_plan_host(A, all, L, 256, false, false, false, -1, &P);
+    if (!err.empty()) { g_err = err; return 1; }
+    run_plan(P, add ? M_ADD : M_SET, nullptr, x, y, nullptr, 0.0, 0.0, 0, nullptr);
+    return 0;
+}
+
+}  // extern "C"
