@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- fine-grid smoother throughput on MI355X (BASELINE.json metric).
+
+One "step" = one relaxation sweep of the reference's Grid::sor row loop
+(grid.cpp:112-145) over the whole fine grid: every interior point updated once,
+in the storage (Gauss-Seidel) order, by the hand-written gfx950 sweep kernel.
+
+Workload at N=1: BASELINE.json configs[2] -- 3-D unit cube, 216^3 = 1.008e7 points,
+K = 50 neighbours per stencil (3-D polyDeg 3), fp64, Dirichlet, multicolour tile
+ordering; the operator is the synthetic kNN-graph Laplacian on exactly that sparsity
+(Grid::build_graph_laplacian): same bytes per row as the RBF-FD Laplacian, values
+do not influence throughput.  All inputs are resident in HBM before the timed region.
+
+N>1 (one process per GPU, torch.distributed/RCCL): weak scaling, every rank owns one
+such sub-domain of an N-times larger cloud; see DESIGN.md "Multi-GPU".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def b_sor(k):
+    """Algorithmic bytes per relaxed row per sweep: 12*K + 28."""
+    return 12 * k + 28
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nside", type=int, default=216, help="points per axis of each rank's cube")
+    ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--polydeg", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(grid, stencil, budget_s):
+    """The oracle's sweep (plain-C port of grid.cpp:112-145, -O3 -march=native,
+    one thread like the reference) on the SAME matrix, for a bounded number of sweeps."""
+    from oracle import oracle_c as oc
+    try:
+        oc.build(fast=True)
+        fast = True
+    except Exception:
+        fast = False
+    la = grid.level_arrays()
+    lv = oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"], la["neumann"],
+                  la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"], fast=fast)
+    interior = int((la["bcflags"] == 0).sum())
+    t0 = time.perf_counter()
+    lv.sor_sweeps(1)
+    t1 = time.perf_counter() - t0
+    n = max(1, min(20, int(budget_s / max(t1, 1e-6)) - 1))
+    t0 = time.perf_counter()
+    lv.sor_sweeps(n)
+    dt = time.perf_counter() - t0
+    return {"value": interior * n / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": f"{n} sweeps over the same {la['n']}-point level (K={stencil}), oracle/mmg_oracle.c "
+                      f"{'-O3 -march=native' if fast else '-O2'}, 1 thread"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from meshlessmultigridpoisson_amd import _capi, _host
+    if _capi.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device (libmmgp has no CPU fallback)")
+    _capi.check(_capi.lib().mmg_set_device(local_rank))
+
+    # ---- setup (untimed): cloud -> ordering -> operator -> packed device layout ----
+    t_setup = time.perf_counter()
+    pts = _host.box_cloud(a.nside, a.dim, seed=12345 + rank)
+    grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC,
+                                    tile_points=a.tile, lanes_per_row=a.lanes)
+    sz = grid.sizes()
+    stencil = sz["stencil"]
+    rng = np.random.default_rng(7 + rank)
+    grid.set_source(rng.standard_normal(sz["a_size"]))
+    lv = _capi.Level.borrow(grid.device_level(), sz["n"], sz["a_size"])
+    info = lv.info()
+    t_setup = time.perf_counter() - t_setup
+    interior = info["sor_rows"]
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        _capi.check(_capi.lib().mmg_synchronize())
+
+    lv.sweeps(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    lv.sweeps(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([float(interior)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_points = float(tot.item())
+    else:
+        total_points = float(interior)
+
+    # dominant kernel: per-launch HIP events on the library's stream
+    kern_ms, launches = lv.time_phases(max(2, min(a.steps, 10)))
+    sweeps_timed = max(2, min(a.steps, 10))
+    alg_bytes = interior * b_sor(stencil) * sweeps_timed
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "fine-grid smoother Mpoints/s + achieved HBM GB/s vs roofline, 1/2/4/8 GPU",
+            "value": total_points * a.steps / dt / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{a.dim}-D unit cube {a.nside}^{a.dim} = {sz['n']} points per GPU, K={stencil} "
+                            f"kNN stencils (graph-Laplacian values on the RBF-FD sparsity), Dirichlet, "
+                            f"one SOR sweep per step (BASELINE configs[2])",
+                "points_per_gpu": sz["n"], "interior_points_per_gpu": int(interior), "stencil": stencil,
+                "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],
+                "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
+                "lds_bytes_per_wave": info["max_lds_bytes"],
+                "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
+                "parallelism": "single" if world == 1 else f"replica-subdomains x{world}",
+                "setup_seconds": round(t_setup, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "tile_kernel<L,MODE_SOR>", "launches": launches,
+                "avg_launch_us": kern_ms * 1e3 / launches,
+                "algorithmic_bytes_per_row": b_sor(stencil),
+            },
+        }
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(grid, stencil, a.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,10 @@ int mmg_level_zero_x(mmg_level *lv);
  * kernels only (measured with per-launch events in a second pass). */
 int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out);
 int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out);
+/* nsweeps sweeps with a hipEvent pair around EVERY sweep-phase kernel launch (the
+ * dominant kernel): *kernel_ms = summed durations, *launches = how many.  The
+ * per-launch average must agree with rocprofv3 --kernel-trace --stats. */
+int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches);
 
 /* ---- transfers == restrictionMatrices_/prolongMatrices_ ------------------- */
 /* The reference stores them column-major (multigrid.h:8-9): pass

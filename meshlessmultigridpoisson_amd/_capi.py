@@ -42,7 +42,7 @@ SYMBOLS = [
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
     "mmg_level_sor", "mmg_level_sweeps", "mmg_level_bound_eval_neumann", "mmg_level_residual",
     "mmg_level_residual_ratio", "mmg_level_boundary_op", "mmg_level_modify_coeff_neumann", "mmg_level_zero_x",
-    "mmg_level_time_sweeps", "mmg_level_time_residual", "mmg_transfer_create", "mmg_transfer_destroy",
+    "mmg_level_time_sweeps", "mmg_level_time_residual", "mmg_level_time_phases", "mmg_transfer_create", "mmg_transfer_destroy",
     "mmg_restrict", "mmg_prolong_add", "mmg_hierarchy_create", "mmg_hierarchy_destroy", "mmg_vcycle",
     "mmg_hierarchy_residual", "mmg_vcycles", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply",
 ]
@@ -79,6 +79,7 @@ def lib():
         L.mmg_level_residual_ratio.argtypes = [vp, _dp]
         L.mmg_level_time_sweeps.argtypes = [vp, C.c_int, C.c_int, _fp]
         L.mmg_level_time_residual.argtypes = [vp, C.c_int, _fp]
+        L.mmg_level_time_phases.argtypes = [vp, C.c_int, _fp, _ip]
         L.mmg_transfer_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _ip, _ip, _dp, C.c_int]
         L.mmg_transfer_destroy.argtypes = [vp]
         L.mmg_transfer_destroy.restype = None
@@ -155,6 +156,15 @@ def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, 
 class Level:
     """Device-side counterpart of one reference `Grid` (hot methods only)."""
 
+    @classmethod
+    def borrow(cls, handle, n, a_size):
+        """Wrap an mmg_level* owned by someone else (a host C++ Grid)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p(handle)
+        self.n, self.a_size = int(n), int(a_size)
+        self._borrowed = True
+        return self
+
     def __init__(self, n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
                  x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0):
         d, keep = make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
@@ -168,9 +178,14 @@ class Level:
             self.set_rhs(b)
 
     def __del__(self):
-        if getattr(self, "h", None) and _lib is not None:
+        if getattr(self, "h", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.mmg_level_destroy(self.h)
             self.h = None
+
+    def time_phases(self, nsweeps):
+        ms, cnt = C.c_float(0), C.c_int(0)
+        check(lib().mmg_level_time_phases(self.h, int(nsweeps), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
 
     def info(self):
         inf = LevelInfo()

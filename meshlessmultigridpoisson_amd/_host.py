@@ -1,0 +1,334 @@
+"""ctypes binding of libmmgp_host.so: the host C++ mirror of the reference's
+Grid / Multigrid classes (csrc/host) through the C harness in csrc/host/harness.cpp.
+Plumbing for tests and bench.py; no compute happens in Python."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmmgp_host.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+_lib = None
+
+ORDER_RCM, ORDER_MC, ORDER_NONE = 0, 1, 2
+KIND_DIRICHLET, KIND_NEUMANN, KIND_GRAPH = 0, 1, 2
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HostError(f"{LIB_PATH} not built (run __graft_entry__.build())")
+        from . import _capi
+        _capi.lib()  # libmmgp.so first (rpath also finds it)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.mmgh_last_error.restype = C.c_char_p
+        L.mmgh_mg_create_square.restype = vp
+        L.mmgh_mg_create_square.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_double, C.c_int, C.c_int, _dp, C.c_int]
+        L.mmgh_mg_destroy.argtypes = [vp]
+        L.mmgh_mg_nlevels.argtypes = [vp]
+        L.mmgh_mg_grid.restype = vp
+        L.mmgh_mg_grid.argtypes = [vp, C.c_int]
+        L.mmgh_mg_vcycle.argtypes = [vp, _dp]
+        L.mmgh_mg_vcycles.argtypes = [vp, C.c_int, _dp, _fp]
+        L.mmgh_mg_residual.argtypes = [vp, _dp]
+        L.mmgh_mg_transfer_shape.argtypes = [vp, C.c_int, C.c_int, _ip, _ip, _ip]
+        L.mmgh_mg_transfer_get.argtypes = [vp, C.c_int, C.c_int, _ip, _ip, _dp]
+        L.mmgh_grid_create_square.restype = vp
+        L.mmgh_grid_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_int, C.c_int, C.c_int]
+        L.mmgh_grid_destroy.argtypes = [vp]
+        L.mmgh_grid_sizes.argtypes = [vp, _ip]
+        L.mmgh_grid_get_csr.argtypes = [vp, _ip, _ip, _dp]
+        L.mmgh_grid_get_points.argtypes = [vp, _dp, _ip]
+        L.mmgh_grid_get_boundaries.argtypes = [vp, _ip, _ip, _ip, _dp]
+        L.mmgh_grid_get_tile_ptr.argtypes = [vp, _ip]
+        for f in ("mmgh_grid_get_values", "mmgh_grid_get_source", "mmgh_grid_set_values", "mmgh_grid_set_source",
+                  "mmgh_grid_residual", "mmgh_grid_residual_ratio"):
+            getattr(L, f).argtypes = [vp, _dp]
+        L.mmgh_grid_set_value_at.argtypes = [vp, C.c_int, C.c_double]
+        L.mmgh_grid_value_at.argtypes = [vp, C.c_int]
+        L.mmgh_grid_value_at.restype = C.c_double
+        for f in ("mmgh_grid_sor", "mmgh_grid_bound_eval_neumann", "mmgh_grid_sor_wrong_args"):
+            getattr(L, f).argtypes = [vp]
+        for f in ("mmgh_grid_boundary_op", "mmgh_grid_modify_coeff_neumann"):
+            getattr(L, f).argtypes = [vp, C.c_int]
+        L.mmgh_grid_device.restype = vp
+        L.mmgh_grid_device.argtypes = [vp]
+        L.mmgh_distance.restype = C.c_double
+        L.mmgh_distance.argtypes = [_dp, _dp]
+        L.mmgh_shifting_scaling.argtypes = [_dp, C.c_int, _dp, _dp]
+        L.mmgh_rcm.argtypes = [_ip, _ip, C.c_int, _ip]
+        L.mmgh_points_from_msh.argtypes = [C.c_char_p, _dp, C.c_int, C.c_int]
+        L.mmgh_bound_pts_conn.argtypes = [C.c_char_p, _ip, C.c_int, _ip]
+        L.mmgh_write_vector_txt.argtypes = [_dp, C.c_int, C.c_char_p]
+        L.mmgh_order_from_txt.argtypes = [C.c_char_p, C.c_int]
+        L.mmgh_write_msh.argtypes = [C.c_char_p, _dp, C.c_int]
+        L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
+        _lib = L
+    return _lib
+
+
+def _err():
+    return lib().mmgh_last_error().decode()
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HostError(_err())
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Grid:
+    """Handle on a C++ `Grid` (csrc/host/grid.h)."""
+
+    def __init__(self, handle, owner=None):
+        self.h = handle
+        self._owner = owner  # a Multigrid owns its grids (multigrid.cpp:10-16)
+
+    @classmethod
+    def create_square(cls, points, polydeg, dim=2, kind=KIND_DIRICHLET, k1=1, k2=1, ordering=ORDER_MC,
+                      tile_points=512, omega=1.4, iters=5, lanes_per_row=0, stencil=0):
+        pts = _d(points).reshape(-1, 3)
+        h = lib().mmgh_grid_create_square(len(pts), pts.ctypes.data_as(_dp), polydeg, dim, kind, k1, k2, ordering,
+                                          tile_points, omega, iters, lanes_per_row, stencil)
+        if not h:
+            raise HostError(_err())
+        g = cls(h)
+        g._own = True
+        return g
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self.h and _lib is not None:
+            _lib.mmgh_grid_destroy(self.h)
+            self.h = None
+
+    def sizes(self):
+        out = np.zeros(8, dtype=np.int32)
+        lib().mmgh_grid_sizes(self.h, out.ctypes.data_as(_ip))
+        return dict(zip(["n", "a_size", "nnz", "neumann", "nb", "nbpts", "n_tiles", "stencil"], out.tolist()))
+
+    def csr(self):
+        s = self.sizes()
+        rowptr = np.zeros(s["a_size"] + 1, dtype=np.int32)
+        col = np.zeros(s["nnz"], dtype=np.int32)
+        val = np.zeros(s["nnz"])
+        lib().mmgh_grid_get_csr(self.h, rowptr.ctypes.data_as(_ip), col.ctypes.data_as(_ip), val.ctypes.data_as(_dp))
+        return rowptr, col, val
+
+    def points(self):
+        s = self.sizes()
+        xyz = np.zeros((s["n"], 3))
+        f = np.zeros(s["n"], dtype=np.int32)
+        lib().mmgh_grid_get_points(self.h, xyz.ctypes.data_as(_dp), f.ctypes.data_as(_ip))
+        return xyz, f
+
+    def boundaries(self):
+        s = self.sizes()
+        btype = np.zeros(s["nb"], dtype=np.int32)
+        bptr = np.zeros(s["nb"] + 1, dtype=np.int32)
+        bpts = np.zeros(s["nbpts"], dtype=np.int32)
+        bvals = np.zeros(s["nbpts"])
+        lib().mmgh_grid_get_boundaries(self.h, btype.ctypes.data_as(_ip), bptr.ctypes.data_as(_ip),
+                                       bpts.ctypes.data_as(_ip), bvals.ctypes.data_as(_dp))
+        return btype, bptr, bpts, bvals
+
+    def tile_ptr(self):
+        s = self.sizes()
+        if s["n_tiles"] == 0:
+            return None
+        tp = np.zeros(s["n_tiles"] + 1, dtype=np.int32)
+        lib().mmgh_grid_get_tile_ptr(self.h, tp.ctypes.data_as(_ip))
+        return tp
+
+    def values(self):
+        x = np.zeros(self.sizes()["a_size"])
+        _chk(lib().mmgh_grid_get_values(self.h, x.ctypes.data_as(_dp)))
+        return x
+
+    def source(self):
+        b = np.zeros(self.sizes()["a_size"])
+        _chk(lib().mmgh_grid_get_source(self.h, b.ctypes.data_as(_dp)))
+        return b
+
+    def set_values(self, x):
+        x = _d(x)
+        assert len(x) == self.sizes()["a_size"]
+        lib().mmgh_grid_set_values(self.h, x.ctypes.data_as(_dp))
+
+    def set_source(self, b):
+        b = _d(b)
+        assert len(b) == self.sizes()["a_size"]
+        lib().mmgh_grid_set_source(self.h, b.ctypes.data_as(_dp))
+
+    def level_arrays(self, omega=1.4, iters=5):
+        """Everything the oracle / the raw C-ABI need, as numpy arrays."""
+        s = self.sizes()
+        rowptr, col, val = self.csr()
+        _xyz, flags = self.points()
+        btype, bptr, bpts, bvals = self.boundaries()
+        return dict(n=s["n"], a_size=s["a_size"], rowptr=rowptr, col=col, val=val, bcflags=flags,
+                    neumann=s["neumann"], omega=omega, iters=iters, btype=btype, bptr=bptr, bpts=bpts, bvals=bvals,
+                    x0=self.values(), b0=self.source())
+
+    # hot methods (device)
+    def sor(self):
+        _chk(lib().mmgh_grid_sor(self.h))
+
+    def boundary_op(self, coarse):
+        _chk(lib().mmgh_grid_boundary_op(self.h, int(coarse)))
+
+    def bound_eval_neumann(self):
+        _chk(lib().mmgh_grid_bound_eval_neumann(self.h))
+
+    def modify_coeff_neumann(self, coarse):
+        _chk(lib().mmgh_grid_modify_coeff_neumann(self.h, int(coarse)))
+
+    def residual(self):
+        r = np.zeros(self.sizes()["a_size"])
+        _chk(lib().mmgh_grid_residual(self.h, r.ctypes.data_as(_dp)))
+        return r
+
+    def residual_ratio(self):
+        v = C.c_double(0)
+        _chk(lib().mmgh_grid_residual_ratio(self.h, C.byref(v)))
+        return v.value
+
+    def device_level(self):
+        """Raw mmg_level* (void*) for direct C-ABI calls (bench timing)."""
+        d = lib().mmgh_grid_device(self.h)
+        if not d:
+            raise HostError(_err())
+        return d
+
+    def knn(self, pid, k):
+        out = np.zeros(k, dtype=np.int32)
+        n = lib().mmgh_grid_knn(self.h, pid, k, out.ctypes.data_as(_ip))
+        return out[:n]
+
+
+class Multigrid:
+    """Handle on a C++ `Multigrid` built by the reference's factory sequence."""
+
+    def __init__(self, clouds, polydegs, dim=2, neumann=False, k1=1, k2=1, ordering=ORDER_MC, tile_points=512,
+                 omega=1.4, iters=5, frac_step=False, bval_abc=None, lanes_per_row=0):
+        npts = _i([len(c) for c in clouds])
+        xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))
+        pd = _i(polydegs)
+        abc = _d(bval_abc) if bval_abc is not None else None
+        self.h = lib().mmgh_mg_create_square(len(clouds), npts.ctypes.data_as(_ip), xyz.ctypes.data_as(_dp),
+                                             pd.ctypes.data_as(_ip), dim, int(neumann), k1, k2, ordering, tile_points,
+                                             omega, iters, int(frac_step),
+                                             abc.ctypes.data_as(_dp) if abc is not None else None, lanes_per_row)
+        if not self.h:
+            raise HostError(_err())
+        self.omega, self.iters = omega, iters
+        self.residuals = []
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmgh_mg_destroy(self.h)
+            self.h = None
+
+    @property
+    def nlevels(self):
+        return lib().mmgh_mg_nlevels(self.h)
+
+    def grid(self, l):
+        return Grid(lib().mmgh_mg_grid(self.h, l), owner=self)
+
+    def transfer(self, which, l):
+        """which: 'R' or 'P'; returns dict(rows, cols, colptr, rowidx, val) or None."""
+        w = 0 if which == "R" else 1
+        r, c, nnz = C.c_int(0), C.c_int(0), C.c_int(0)
+        if lib().mmgh_mg_transfer_shape(self.h, w, l, C.byref(r), C.byref(c), C.byref(nnz)):
+            return None
+        colptr = np.zeros(c.value + 1, dtype=np.int32)
+        rowidx = np.zeros(nnz.value, dtype=np.int32)
+        val = np.zeros(nnz.value)
+        lib().mmgh_mg_transfer_get(self.h, w, l, colptr.ctypes.data_as(_ip), rowidx.ctypes.data_as(_ip),
+                                   val.ctypes.data_as(_dp))
+        return dict(rows=r.value, cols=c.value, colptr=colptr, rowidx=rowidx, val=val)
+
+    def vcycle(self):
+        v = C.c_double(0)
+        _chk(lib().mmgh_mg_vcycle(self.h, C.byref(v)))
+        if v.value >= 0:
+            self.residuals.append(v.value)
+        return v.value
+
+    def vcycles(self, n):
+        res = np.zeros(n)
+        ms = C.c_float(0)
+        _chk(lib().mmgh_mg_vcycles(self.h, n, res.ctypes.data_as(_dp), C.byref(ms)))
+        self.residuals.extend(res.tolist())
+        return res, ms.value
+
+    def residual(self):
+        v = C.c_double(0)
+        _chk(lib().mmgh_mg_residual(self.h, C.byref(v)))
+        return v.value
+
+    def oracle(self):
+        """The same hierarchy as CPU-oracle objects (tests / smoke / cpu_baseline only)."""
+        from oracle import oracle_c as oc
+        nl = self.nlevels
+        levels = []
+        for l in range(nl):
+            la = self.grid(l).level_arrays(self.omega, self.iters)
+            levels.append(oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"],
+                                   la["neumann"], la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"],
+                                   la["bvals"]))
+        R, P = [None] * nl, [None] * nl
+        for l in range(nl):
+            t = self.transfer("R", l)
+            if t:
+                R[l] = oc.Transfer.from_dict(t)
+            t = self.transfer("P", l)
+            if t:
+                P[l] = oc.Transfer.from_dict(t)
+        return oc.Multigrid(levels, R, P)
+
+
+# ---- synthetic clouds (vectorised; seeds per SURVEY 8d) ------------------------------------
+def square_cloud(nside, seed=12345, jitter=0.25):
+    """nside^2 lattice on [0,1]^2, interior jittered by +-jitter*h, boundary coordinates
+    exactly 0/1 (the reference detects boundaries by exact compares, testing_functions.cpp:86)."""
+    return box_cloud(nside, 2, seed, jitter)
+
+
+def box_cloud(nside, dim, seed=12345, jitter=0.25):
+    rng = np.random.default_rng(seed)
+    h = 1.0 / (nside - 1)
+    ax = np.arange(nside) * h
+    ax[-1] = 1.0
+    if dim == 2:
+        Y, X = np.meshgrid(ax, ax, indexing="ij")
+        pts = np.stack([X.ravel(), Y.ravel(), np.zeros(nside * nside)], axis=1)
+        idx = np.stack(np.meshgrid(np.arange(nside), np.arange(nside), indexing="ij"), axis=-1).reshape(-1, 2)
+    else:
+        Z, Y, X = np.meshgrid(ax, ax, ax, indexing="ij")
+        pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+        idx = np.stack(np.meshgrid(np.arange(nside), np.arange(nside), np.arange(nside), indexing="ij"), axis=-1).reshape(-1, 3)
+    interior = np.all((idx > 0) & (idx < nside - 1), axis=1)
+    jit = (rng.random((len(pts), dim)) * 2 - 1) * jitter * h
+    pts[interior, :dim] += jit[interior]
+    return pts

@@ -626,6 +626,50 @@ int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
     return rc;
 }
 
+int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches)
+{
+    if (!lv || !kernel_ms || !launches || nsweeps < 1) return fail(MMG_ERR_INVALID, "bad argument");
+    const int nph = lv->A.n_phases();
+    const int total = nph * nsweeps;
+    std::vector<hipEvent_t> ev((size_t)total * 2);
+    for (auto &e : ev) HIPC(hipEventCreate(&e));
+    TileArgs a{};
+    a.p = lv->A.dev;
+    a.in = lv->x.p;
+    a.out = lv->x.p;
+    a.b = lv->b.p;
+    a.omega = lv->omega;
+    a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
+    a.flags8 = lv->flags8.p;
+    a.partial = lv->neumann ? lv->partX.p : nullptr;
+    int k = 0;
+    for (int it = 0; it < nsweeps; ++it) {
+        for (int ph = 0; ph < nph; ++ph) {
+            a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
+            a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+            HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
+            HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+            HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
+            ++k;
+        }
+        if (lv->neumann)
+            HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+        int rc = bound_eval(lv);
+        if (rc) return rc;
+    }
+    HIPC(hipStreamSynchronize(g_stream));
+    double sum = 0.0;
+    for (int i = 0; i < total; ++i) {
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]));
+        sum += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    *kernel_ms = (float)sum;
+    *launches = total;
+    return MMG_OK;
+}
+
 int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out)
 {
     if (!lv || !ms_out || reps < 1) return fail(MMG_ERR_INVALID, "bad argument");

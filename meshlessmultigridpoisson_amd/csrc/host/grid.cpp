@@ -1,0 +1,627 @@
+// grid.cpp -- see grid.h.  Setup follows MeshlessPoisson/grid.cpp (citations per
+// method); the hot methods forward to the C-ABI of libmmgp.so.
+#include "grid.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <stdexcept>
+#include <thread>
+
+#include "../../../include/mmgp.h"
+
+using mmgh::Mat;
+using mmgh::Sparse;
+using mmgh::Triplet;
+using mmgh::Vec;
+
+namespace {
+void dev_check(int rc, const char *what)
+{
+    if (rc != MMG_OK) throw std::runtime_error(std::string(what) + ": " + mmg_last_error());
+}
+
+template <class F>
+void parallel_for(int n, int nthreads, F f)
+{
+    if (nthreads <= 1 || n < 64) {
+        for (int i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int b = next.fetch_add(16);
+                if (b >= n) break;
+                const int e = std::min(n, b + 16);
+                for (int i = b; i < e; ++i) f(i);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
+int Grid::polyTerms(int polyDeg, int dim)
+{
+    return dim >= 3 ? (polyDeg + 1) * (polyDeg + 2) * (polyDeg + 3) / 6 : (polyDeg + 1) * (polyDeg + 2) / 2;
+}
+// grid.cpp:266-267: int(2.5 * polyTerms)
+int Grid::stencilSizeFor(int polyDeg, int dim) { return (int)(2.5 * polyTerms(polyDeg, dim)); }
+
+// grid.cpp:5-27
+Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source)
+{
+    const int numPoint = (int)points.size();
+    points_ = std::move(points);
+    boundaries_ = std::move(boundaries);
+    properties_ = properties;
+    source_ = source;
+    neumannFlag_ = false;
+    implicitFlag_ = false;  // uninitialised in the reference; its factories always assign it
+    setNeumannFlag();
+    laplaceMatSize_ = numPoint;
+    const int A_size = neumannFlag_ ? numPoint + 1 : numPoint;
+    bcFlags_ = vector<int>((size_t)numPoint, 0);
+    normalVecs_ = vector<Point>((size_t)numPoint);
+    laplaceMat_ = new SparseRowMajor(A_size, A_size, true);
+    values_ = new VectorXd((size_t)A_size);
+    residuals_ = nullptr;
+    neumann_boundary_coeffs_ = new SparseRowMajor(A_size, A_size, true);
+    diags = VectorXd((size_t)A_size);
+}
+
+Grid::~Grid()
+{
+    invalidate_device();
+    delete values_;
+    delete laplaceMat_;
+    delete neumann_boundary_coeffs_;
+}
+
+int Grid::threads() const
+{
+    int t = setup_threads_ > 0 ? setup_threads_ : (int)std::thread::hardware_concurrency();
+    return std::max(1, t);
+}
+
+// grid.cpp:33-40
+void Grid::setBCFlag(int bNum, std::string type, vector<double> boundValues)
+{
+    Boundary &bound = boundaries_.at((size_t)bNum);
+    bound.type = type.compare("dirichlet") == 0 ? 1 : 2;
+    for (int p : bound.bcPoints) bcFlags_[(size_t)p] = bound.type;
+    bound.values = std::move(boundValues);
+    invalidate_device();
+}
+
+// grid.cpp:52-60
+void Grid::setNeumannFlag()
+{
+    neumannFlag_ = false;
+    for (const Boundary &b : boundaries_)
+        if (b.type == 2) { neumannFlag_ = true; return; }
+}
+
+int Grid::getSize() { return laplaceMatSize_; }
+int Grid::getStencilSize() { return properties_.stencilSize; }
+int Grid::getPolyDeg() { return properties_.polyDeg; }
+
+vector<Point> Grid::pointIDs_to_vector(const vector<int> &ids)
+{
+    vector<Point> out;
+    out.reserve(ids.size());
+    for (int i : ids) out.push_back(points_[(size_t)i]);
+    return out;
+}
+
+void Grid::ensure_knn()
+{
+    if (!knn_.ready()) knn_ = mmgh::CellGrid(points_, dim_);
+}
+
+// grid.cpp:213-215
+vector<int> Grid::kNearestNeighbors(int pointID, bool neumann, int stencilSize)
+{
+    return kNearestNeighbors(points_[(size_t)pointID], neumann, bcFlags_[(size_t)pointID] != 0, stencilSize);
+}
+
+// grid.cpp:216-260 -- k smallest (distance, index); for a boundary point of a
+// Neumann grid all other boundary points are skipped.  Cell-grid search instead
+// of the reference's full scan, identical result.
+vector<int> Grid::kNearestNeighbors(Point refPoint, bool neumann, bool pointBCFlag, int stencilSize)
+{
+    ensure_knn();
+    std::vector<std::pair<double, int>> res;
+    std::function<bool(int)> excl;
+    if (pointBCFlag && neumann) excl = [this](int i) { return bcFlags_[(size_t)i] != 0; };
+    knn_.knn(refPoint, stencilSize, excl, res);
+    vector<int> out;
+    out.reserve(res.size());
+    for (auto &r : res) out.push_back(r.second);
+    return out;
+}
+
+// grid.cpp:263-303 -- PHS r^m block + polynomial block of the saddle system
+std::tuple<Mat, vector<int>, vector<Point>> Grid::buildCoeffMatrix(Point point, bool neumann, bool pointBCFlag, int polyDeg)
+{
+    const int pt = polyTerms(polyDeg, dim_);
+    const int ss = stencilSizeFor(polyDeg, dim_);
+    vector<int> nb = kNearestNeighbors(point, neumann, pointBCFlag, ss);
+    vector<Point> sp = shifting_scaling_dim(pointIDs_to_vector(nb), point, dim_);
+    Mat m = Mat::Zero(ss + pt, ss + pt);
+    for (int i = 0; i < ss; ++i)
+        for (int j = i; j < ss; ++j) {
+            const double a = std::pow(distance_dim(sp[(size_t)i], sp[(size_t)j], dim_), properties_.rbfExp);
+            m(i, j) = a;
+            m(j, i) = a;
+        }
+    for (int row = 0; row < ss; ++row) {
+        const double x = std::get<0>(sp[(size_t)row]), y = std::get<1>(sp[(size_t)row]), z = std::get<2>(sp[(size_t)row]);
+        int c = ss;
+        for (int p = 0; p <= polyDeg; ++p)
+            for (int q = 0; q <= p; ++q) {
+                if (dim_ < 3) {
+                    const double v = std::pow(x, p - q) * std::pow(y, q);
+                    m(row, c) = v;
+                    m(c, row) = v;
+                    ++c;
+                } else {
+                    for (int s = 0; s <= q; ++s) {
+                        const double v = std::pow(x, p - q) * std::pow(y, q - s) * std::pow(z, s);
+                        m(row, c) = v;
+                        m(c, row) = v;
+                        ++c;
+                    }
+                }
+            }
+    }
+    return std::make_tuple(std::move(m), std::move(nb), std::move(sp));
+}
+
+std::tuple<Mat, vector<int>, vector<Point>> Grid::buildCoeffMatrix(int pointID, bool neumann, int polyDeg)
+{
+    return buildCoeffMatrix(points_[(size_t)pointID], neumann, bcFlags_[(size_t)pointID] != 0, polyDeg);
+}
+
+// Right-hand sides of grid.cpp:304-424 and :687-712, one factorisation.
+std::pair<Vec, vector<int>> Grid::stencil_weights(Point point, bool neumann, bool pointBCFlag, int polyDeg, Op op)
+{
+    auto coeffs = buildCoeffMatrix(point, neumann, pointBCFlag, polyDeg);
+    const vector<int> &nb = std::get<1>(coeffs);
+    const vector<Point> &sp = std::get<2>(coeffs);
+    const int pt = polyTerms(polyDeg, dim_);
+    const int ss = stencilSizeFor(polyDeg, dim_);
+    std::vector<double> rhs((size_t)(ss + pt), 0.0);
+    const Point ev = sp.back();
+    const double xe = std::get<0>(ev), ye = std::get<1>(ev), ze = std::get<2>(ev);
+    const double M = (double)properties_.rbfExp;
+    for (int i = 0; i < ss; ++i) {
+        const double xr = std::get<0>(sp[(size_t)i]), yr = std::get<1>(sp[(size_t)i]), zr = std::get<2>(sp[(size_t)i]);
+        if (op == OP_LAPLACE) {  // grid.cpp:394-402
+            double D = xe * xe - 2 * xe * xr + xr * xr + ye * ye - 2 * ye * yr + yr * yr;
+            double g2 = std::pow(2 * xe - 2 * xr, 2) + std::pow(2 * ye - 2 * yr, 2);
+            if (dim_ >= 3) {
+                D += ze * ze - 2 * ze * zr + zr * zr;
+                g2 += std::pow(2 * ze - 2 * zr, 2);
+            }
+            if (D > 0) rhs[(size_t)i] = g2 * (M / 2) * (M / 2 - 1) * std::pow(D, M / 2 - 2) + dim_ * M * std::pow(D, M / 2 - 1);
+        } else if (op == OP_INTERP) {  // grid.cpp:699-701
+            rhs[(size_t)i] = std::pow(distance_dim(ev, sp[(size_t)i], dim_), properties_.rbfExp);
+        } else if (i > 0) {  // grid.cpp:320-322 / :359-361 (entry 0 assumed to be the point itself)
+            const double delta = op == OP_DX ? (xe - xr) : (op == OP_DY ? (ye - yr) : (ze - zr));
+            rhs[(size_t)i] = M * std::pow(distance_dim(sp[(size_t)i], ev, dim_), M - 2) * delta;
+        }
+    }
+    int r = ss;
+    auto mono = [&](int a, int b, int c) {  // exponents of x, y, z
+        double v = 0.0;
+        if (op == OP_INTERP) v = std::pow(xe, a) * std::pow(ye, b) * std::pow(ze, c);
+        else if (op == OP_DX) { if (a - 1 >= 0) v = a * std::pow(xe, a - 1) * std::pow(ye, b) * std::pow(ze, c); }
+        else if (op == OP_DY) { if (b - 1 >= 0) v = b * std::pow(xe, a) * std::pow(ye, b - 1) * std::pow(ze, c); }
+        else if (op == OP_DZ) { if (c - 1 >= 0) v = c * std::pow(xe, a) * std::pow(ye, b) * std::pow(ze, c - 1); }
+        else {
+            if (a - 2 >= 0) v += a * (a - 1) * std::pow(xe, a - 2) * std::pow(ye, b) * std::pow(ze, c);
+            if (b - 2 >= 0) v += b * (b - 1) * std::pow(xe, a) * std::pow(ye, b - 2) * std::pow(ze, c);
+            if (c - 2 >= 0) v += c * (c - 1) * std::pow(xe, a) * std::pow(ye, b) * std::pow(ze, c - 2);
+        }
+        return v;
+    };
+    for (int p = 0; p <= polyDeg; ++p)
+        for (int q = 0; q <= p; ++q) {
+            if (dim_ < 3) rhs[(size_t)r++] = mono(p - q, q, 0);
+            else
+                for (int s = 0; s <= q; ++s) rhs[(size_t)r++] = mono(p - q, q - s, s);
+        }
+    std::vector<std::vector<double>> sys(1, std::move(rhs));
+    mmgh::full_piv_lu_solve(std::get<0>(coeffs), sys);
+    Vec w((size_t)(ss + pt));
+    std::vector<double> &wv = w.host_mut();
+    wv = sys[0];
+    const double scale = std::get<0>(sp[sp.size() - 2]);
+    if (op == OP_LAPLACE) for (double &v : wv) v /= std::pow(scale, 2);
+    else if (op != OP_INTERP) for (double &v : wv) v /= scale;
+    return std::make_pair(std::move(w), nb);
+}
+
+std::pair<Vec, vector<int>> Grid::laplaceWeights(int id)
+{
+    return stencil_weights(points_[(size_t)id], neumannFlag_, bcFlags_[(size_t)id] != 0, properties_.polyDeg, OP_LAPLACE);
+}
+std::pair<Vec, vector<int>> Grid::derivx_weights(int id)
+{
+    return stencil_weights(points_[(size_t)id], neumannFlag_, bcFlags_[(size_t)id] != 0, properties_.polyDeg, OP_DX);
+}
+std::pair<Vec, vector<int>> Grid::derivy_weights(int id)
+{
+    return stencil_weights(points_[(size_t)id], neumannFlag_, bcFlags_[(size_t)id] != 0, properties_.polyDeg, OP_DY);
+}
+std::pair<Vec, vector<int>> Grid::derivz_weights(int id)
+{
+    return stencil_weights(points_[(size_t)id], neumannFlag_, bcFlags_[(size_t)id] != 0, properties_.polyDeg, OP_DZ);
+}
+std::pair<Vec, vector<int>> Grid::pointInterpWeights(Point point, int polyDeg)
+{
+    return stencil_weights(point, false, false, polyDeg, OP_INTERP);
+}
+
+// grid.cpp:442-518 -- geometric inward normals; unit square / cube faces plus the
+// two circular geometries of the reference.
+void Grid::build_normal_vecs(const char *, std::string geomtype)
+{
+    for (int p : boundaries_[0].bcPoints) {
+        const double x = std::get<0>(points_[(size_t)p]), y = std::get<1>(points_[(size_t)p]), z = std::get<2>(points_[(size_t)p]);
+        if (y == 0) normalVecs_[(size_t)p] = std::make_tuple(0, 1, 0);
+        else if (y == 1) normalVecs_[(size_t)p] = std::make_tuple(0, -1, 0);
+        else if (x == 0) normalVecs_[(size_t)p] = std::make_tuple(1, 0, 0);
+        else if (x == 1) normalVecs_[(size_t)p] = std::make_tuple(-1, 0, 0);
+        else if (dim_ >= 3 && z == 0) normalVecs_[(size_t)p] = std::make_tuple(0, 0, 1);
+        else if (dim_ >= 3 && z == 1) normalVecs_[(size_t)p] = std::make_tuple(0, 0, -1);
+    }
+    auto radial = [&](const Boundary &b, double sign) {
+        for (int p : b.bcPoints) {
+            double x = std::get<0>(points_[(size_t)p]) - 0.5, y = std::get<1>(points_[(size_t)p]) - 0.5;
+            const double nrm = std::sqrt(x * x + y * y);
+            x /= nrm;
+            y /= nrm;
+            normalVecs_[(size_t)p] = std::make_tuple(sign * x, sign * y, 0);
+        }
+    };
+    if (geomtype.compare("square_with_circle") == 0) radial(boundaries_[1], 1.0);
+    else if (geomtype.compare("concentric_circles") == 0) {
+        radial(boundaries_[0], -1.0);
+        radial(boundaries_[1], 1.0);
+    }
+}
+
+// grid.cpp:520-548 -- n . grad stencil of every Neumann point
+void Grid::build_deriv_normal_bound()
+{
+    deriv_normal_coeffs_.clear();
+    vector<std::pair<int, double>> todo;  // (point, value) in the reference's order
+    for (const Boundary &b : boundaries_)
+        if (b.type == 2)
+            for (size_t j = 0; j < b.bcPoints.size(); ++j) todo.emplace_back(b.bcPoints[j], b.values[j]);
+    deriv_normal_coeffs_.resize(todo.size());
+    ensure_knn();
+    parallel_for((int)todo.size(), threads(), [&](int k) {
+        const int p = todo[(size_t)k].first;
+        auto cx = derivx_weights(p);
+        auto cy = derivy_weights(p);
+        const double nx = std::get<0>(normalVecs_[(size_t)p]), ny = std::get<1>(normalVecs_[(size_t)p]);
+        Vec w = cx.first * nx;
+        w += cy.first * ny;
+        if (dim_ >= 3) w += derivz_weights(p).first * std::get<2>(normalVecs_[(size_t)p]);
+        deriv_normal_bc &d = deriv_normal_coeffs_[(size_t)k];
+        d.pointID = p;
+        d.value = todo[(size_t)k].second;
+        d.weights = w;
+        d.neighbors = cx.second;
+    });
+}
+
+// grid.cpp:549-663
+void Grid::build_laplacian()
+{
+    invalidate_device();
+    const int n = laplaceMatSize_;
+    ensure_knn();
+    std::vector<std::vector<double>> W((size_t)n);
+    std::vector<vector<int>> NB((size_t)n);
+    parallel_for(n, threads(), [&](int i) {
+        auto w = laplaceWeights(i);
+        W[(size_t)i] = w.first.host();
+        NB[(size_t)i] = std::move(w.second);
+    });
+    vector<Triplet> trip, btrip;
+    trip.reserve((size_t)n * (size_t)(properties_.stencilSize + 2));
+    for (int i = 0; i < n; ++i) {
+        if (bcFlags_[(size_t)i] != 2) {
+            for (size_t j = 0; j < NB[(size_t)i].size(); ++j) {
+                const int c = NB[(size_t)i][j];
+                const double v = W[(size_t)i][j];
+                trip.emplace_back(i, c, v);
+                if (bcFlags_[(size_t)i] == 0 && bcFlags_[(size_t)c] == 2) btrip.emplace_back(i, c, v);
+                if (i == c) diags.coeffRef(i) = v;
+            }
+        }
+        if (neumannFlag_ && bcFlags_[(size_t)i] != 2) trip.emplace_back(i, n, 1.0);
+        std::vector<double>().swap(W[(size_t)i]);
+    }
+    if (neumannFlag_) {
+        for (int i = 0; i < n + 1; ++i)
+            if (i == n || bcFlags_[(size_t)i] != 2) trip.emplace_back(n, i, 1.0);
+        for (const deriv_normal_bc &b : deriv_normal_coeffs_)
+            for (size_t j = 0; j < b.neighbors.size(); ++j) {
+                trip.emplace_back(b.pointID, b.neighbors[j], b.weights.coeff((long)j));
+                if (b.pointID == b.neighbors[j]) diags.coeffRef(b.pointID) = b.weights.coeff((long)j);
+            }
+    }
+    laplaceMat_->setFromTriplets(trip.begin(), trip.end());
+    neumann_boundary_coeffs_->setFromTriplets(btrip.begin(), btrip.end());
+    if (!implicitFlag_) return;
+
+    // implicit elimination of the Neumann unknowns from the interior rows (:598-661)
+    const double *val = laplaceMat_->valuePtr();
+    const int *col = laplaceMat_->innerIndexPtr();
+    const int *rp = laplaceMat_->outerIndexPtr();
+    const int rows = laplaceMat_->rows();
+    for (int i = 0; i < rows - 1; ++i) {
+        if (bcFlags_[(size_t)i] != 0) continue;
+        vector<std::pair<int, double>> bnd;
+        for (int p = rp[i]; p < rp[i + 1]; ++p)
+            if (col[p] != rows - 1 && bcFlags_[(size_t)col[p]] == 2) bnd.emplace_back(col[p], val[p]);
+        for (auto &jb : bnd) {
+            const int jc = jb.first;
+            const double A_ij = jb.second, A_jj = diags.coeff(jc);
+            for (int p = rp[jc]; p < rp[jc + 1]; ++p) {
+                if (col[p] == jc) continue;
+                trip.emplace_back(i, col[p], -val[p] * A_ij / A_jj);
+            }
+            trip.emplace_back(i, jc, -A_ij);
+        }
+    }
+    delete laplaceMat_;
+    laplaceMat_ = new SparseRowMajor((int)points_.size() + 1, (int)points_.size() + 1, true);
+    laplaceMat_->setFromTriplets(trip.begin(), trip.end());
+}
+
+void Grid::build_graph_laplacian()
+{
+    invalidate_device();
+    if (neumannFlag_) throw std::invalid_argument("build_graph_laplacian: Dirichlet grids only");
+    const int n = laplaceMatSize_;
+    const int K = properties_.stencilSize;
+    ensure_knn();
+    std::vector<int> outer((size_t)n + 1, 0), inner((size_t)n * (size_t)K);
+    std::vector<double> val((size_t)n * (size_t)K);
+    for (int i = 0; i <= n; ++i) outer[(size_t)i] = i * K;
+    double h2 = 1.0 / std::pow((double)n, 2.0 / dim_);
+    parallel_for(n, threads(), [&](int i) {
+        std::vector<std::pair<double, int>> res;
+        knn_.knn(points_[(size_t)i], K, std::function<bool(int)>(), res);
+        std::vector<std::pair<int, double>> row;
+        row.reserve(res.size());
+        double sum = 0.0;
+        for (auto &r : res) {
+            if (r.second == i) continue;
+            const double w = h2 / std::max(r.first * r.first, 1e-300);
+            row.emplace_back(r.second, w);
+            sum += w;
+        }
+        row.emplace_back(i, -sum);
+        std::sort(row.begin(), row.end());
+        for (size_t k = 0; k < row.size(); ++k) {
+            inner[(size_t)i * K + k] = row[k].first;
+            val[(size_t)i * K + k] = row[k].second;
+        }
+    });
+    delete laplaceMat_;
+    laplaceMat_ = new SparseRowMajor(n, n, true);
+    laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(val));
+}
+
+// grid.cpp:664-685
+void Grid::push_inhomog_to_rhs()
+{
+    if (!implicitFlag_) return;
+    const double *val = neumann_boundary_coeffs_->valuePtr();
+    const int *col = neumann_boundary_coeffs_->innerIndexPtr();
+    const int *rp = neumann_boundary_coeffs_->outerIndexPtr();
+    const std::vector<double> copy = source_.host();
+    std::vector<double> &src = source_.host_mut();
+    for (int i = 0; i < laplaceMatSize_; ++i) {
+        if (bcFlags_[(size_t)i] != 0) continue;
+        for (int p = rp[i]; p < rp[i + 1]; ++p) src[(size_t)i] -= val[p] * copy[(size_t)col[p]] / diags.coeff(col[p]);
+    }
+}
+
+// grid.cpp:744-774
+void Grid::apply_order(const vector<int> &order)
+{
+    const size_t n = points_.size();
+    if (order.size() != n) throw std::invalid_argument("apply_order: permutation size mismatch");
+    invalidate_device();
+    vector<Point> np(n), nn(n);
+    vector<int> nf(n), old2new(n);
+    std::vector<double> &src = source_.host_mut();
+    std::vector<double> ns(src);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t o = (size_t)order[i];
+        np[i] = points_[o];
+        nf[i] = bcFlags_[o];
+        ns[i] = src[o];
+        nn[i] = normalVecs_[o];
+        old2new[o] = (int)i;
+    }
+    points_.swap(np);
+    src.swap(ns);
+    bcFlags_.swap(nf);
+    normalVecs_.swap(nn);
+    for (Boundary &b : boundaries_)
+        for (int &p : b.bcPoints) p = old2new[(size_t)p];
+    knn_ = mmgh::CellGrid();
+    tile_ptr_.clear();
+}
+
+// grid.cpp:713-776
+void Grid::rcm_order_points()
+{
+    const int n = (int)points_.size();
+    ensure_knn();
+    vector<vector<int>> adj((size_t)n);
+    parallel_for(n, threads(), [&](int i) {
+        adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
+    });
+    if (neumannFlag_ && implicitFlag_) {
+        for (int i = 0; i < n; ++i) {
+            if (bcFlags_[(size_t)i] != 0) continue;
+            for (size_t j = 0; j < adj[(size_t)i].size(); ++j) {  // grows while scanned (:727-733)
+                const int a = adj[(size_t)i][j];
+                if (bcFlags_[(size_t)a] != 2) continue;
+                for (int k : adj[(size_t)a])
+                    if (std::find(adj[(size_t)i].begin(), adj[(size_t)i].end(), k) == adj[(size_t)i].end()) adj[(size_t)i].push_back(k);
+            }
+        }
+    }
+    vector<int> order((size_t)n);
+    reverse_cuthill_mckee_ordering(adj, order);
+    apply_order(order);
+}
+
+// grid.cpp:197-205 (host-side helper kept for call-site compatibility)
+void Grid::fix_vector_bound_coarse(VectorXd *vec)
+{
+    for (const Boundary &b : boundaries_)
+        if (b.type == 1)
+            for (int p : b.bcPoints) vec->coeffRef(p) = 0;
+}
+
+// ---------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------
+void Grid::invalidate_device()
+{
+    if (dev_) {
+        values_->detach();
+        source_.detach();
+        mmg_level_destroy(dev_);
+        dev_ = nullptr;
+    }
+}
+
+mmg_level *Grid::device()
+{
+    if (dev_) return dev_;
+    mmg_level_desc d{};
+    d.n = laplaceMatSize_;
+    d.a_size = laplaceMat_->rows();
+    d.rowptr = laplaceMat_->outerIndexPtr();
+    d.col = laplaceMat_->innerIndexPtr();
+    d.val = laplaceMat_->valuePtr();
+    d.bcflags = bcFlags_.data();
+    d.neumann_flag = neumannFlag_ ? 1 : 0;
+    d.omega = properties_.omega;
+    d.iters = properties_.iters;
+    vector<int> btype, bptr(1, 0), bpts;
+    vector<double> bvals;
+    for (const Boundary &b : boundaries_) {
+        btype.push_back(b.type);
+        bpts.insert(bpts.end(), b.bcPoints.begin(), b.bcPoints.end());
+        for (size_t j = 0; j < b.bcPoints.size(); ++j) bvals.push_back(j < b.values.size() ? b.values[j] : 0.0);
+        bptr.push_back((int)bpts.size());
+    }
+    d.nb = (int)btype.size();
+    d.btype = btype.data();
+    d.bptr = bptr.data();
+    d.bpts = bpts.data();
+    d.bvals = bvals.data();
+    if (!tile_ptr_.empty()) {
+        d.tile_ptr = tile_ptr_.data();
+        d.n_tiles = (int)tile_ptr_.size() - 1;
+    }
+    d.tile_size = tile_size_;
+    d.lanes_per_row = lanes_per_row_;
+    dev_check(mmg_level_create(&dev_, &d), "mmg_level_create");
+    mmg_level *h = dev_;
+    values_->attach([h](double *dst, size_t cnt) { dev_check(mmg_level_get_x(h, dst, (int)cnt), "mmg_level_get_x"); });
+    source_.attach([h](double *dst, size_t cnt) { dev_check(mmg_level_get_rhs(h, dst, (int)cnt), "mmg_level_get_rhs"); });
+    // a fresh device level holds nothing: force the first upload
+    values_->host_mut();
+    source_.host_mut();
+    return dev_;
+}
+
+void Grid::sync_to_device()
+{
+    mmg_level *h = device();
+    dev_check(mmg_level_set_omega_iters(h, properties_.omega, properties_.iters), "mmg_level_set_omega_iters");
+    if (values_->host_newer()) {
+        dev_check(mmg_level_set_x(h, values_->data(), (int)values_->rows()), "mmg_level_set_x");
+        values_->mark_uploaded();
+    }
+    if (source_.host_newer()) {
+        dev_check(mmg_level_set_rhs(h, source_.data(), (int)source_.rows()), "mmg_level_set_rhs");
+        source_.mark_uploaded();
+    }
+}
+
+void Grid::mark_values_on_device() { values_->mark_device_newer(); }
+void Grid::mark_source_on_device() { source_.mark_device_newer(); }
+
+void Grid::boundaryOp(std::string coarse)
+{
+    sync_to_device();
+    dev_check(mmg_level_boundary_op(dev_, coarse.compare("coarse") == 0), "mmg_level_boundary_op");
+    mark_values_on_device();
+}
+
+void Grid::modify_coeff_neumann(std::string coarse)
+{
+    if (!dev_) {  // setup-time use by the grid factories (testing_functions.cpp:279): no device image yet
+        for (const Boundary &b : boundaries_)
+            if (b.type == 2)
+                for (size_t j = 0; j < b.bcPoints.size(); ++j)
+                    source_.coeffRef(b.bcPoints[j]) = coarse.compare("coarse") == 0 ? 0 : b.values.at(j);
+        source_.coeffRef(source_.rows() - 1) = 0;
+        return;
+    }
+    sync_to_device();
+    dev_check(mmg_level_modify_coeff_neumann(dev_, coarse.compare("coarse") == 0), "mmg_level_modify_coeff_neumann");
+    mark_source_on_device();
+}
+
+void Grid::bound_eval_neumann()
+{
+    sync_to_device();
+    dev_check(mmg_level_bound_eval_neumann(dev_), "mmg_level_bound_eval_neumann");
+    mark_values_on_device();
+}
+
+void Grid::sor(SparseRowMajor *matrix, VectorXd *values, VectorXd *rhs)
+{
+    // every reference call site passes the grid's own members (multigrid.cpp:79,94,95,108;
+    // testing_functions.cpp:440); anything else has no device image.
+    if (matrix != laplaceMat_ || values != values_ || rhs != &source_)
+        throw std::invalid_argument("Grid::sor: only (laplaceMat_, values_, &source_) is supported on the device path");
+    sync_to_device();
+    dev_check(mmg_level_sor(dev_), "mmg_level_sor");
+    mark_values_on_device();
+}
+
+Grid::VectorXd Grid::residual()
+{
+    sync_to_device();
+    VectorXd r((size_t)laplaceMat_->rows());
+    dev_check(mmg_level_residual(dev_, r.host_mut().data(), (int)r.rows()), "mmg_level_residual");
+    return r;
+}
+
+double Grid::residual_ratio()
+{
+    sync_to_device();
+    double v = 0;
+    dev_check(mmg_level_residual_ratio(dev_, &v), "mmg_level_residual_ratio");
+    return v;
+}

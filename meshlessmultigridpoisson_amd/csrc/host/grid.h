@@ -1,0 +1,127 @@
+// grid.h -- host-side mirror of the reference's `Grid` (MeshlessPoisson/grid.h:20-79):
+// same public member names and call semantics, so the reference's call sites
+// (testing_functions.cpp:68-284,329-343,431-442; FractionalStepSim.cpp:3-49)
+// compile against it after replacing the Eigen type names.  Setup runs on the
+// host (multi-threaded, spatially hashed instead of O(N^2)); the hot methods
+// sor / residual / bound_eval_neumann / boundaryOp / modify_coeff_neumann /
+// fix_vector_bound_coarse run on the MI355X through the C-ABI of libmmgp.so.
+// There is no CPU fallback for the hot methods.
+#ifndef MMGH_GRID_H
+#define MMGH_GRID_H
+#include <memory>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "fileReadingFunctions.h"
+#include "general_computation_functions.h"
+#include "gridclasses.hpp"
+#include "knn.hpp"
+#include "la.hpp"
+
+struct mmg_level;  // include/mmgp.h
+
+using std::vector;
+
+class Grid {
+public:
+    typedef mmgh::Vec VectorXd;
+    typedef mmgh::Sparse SparseRowMajor;
+    typedef mmgh::Mat MatrixXd;
+
+    // ---- the reference's public state (grid.h:23-38), same names ------------
+    VectorXd *values_;
+    VectorXd *residuals_;  // never used by the reference either
+    VectorXd source_;
+    vector<Point> points_;
+    vector<Boundary> boundaries_;
+    vector<Point> normalVecs_;
+    vector<deriv_normal_bc> deriv_normal_coeffs_;
+    GridProperties properties_;
+    vector<std::pair<int, int>> ptsConn_;
+    int laplaceMatSize_;
+    SparseRowMajor *laplaceMat_;
+    SparseRowMajor *neumann_boundary_coeffs_;
+    VectorXd diags;
+    vector<int> bcFlags_;
+    bool neumannFlag_;
+    bool implicitFlag_;
+    vector<double> cond_rbf;
+
+    // ---- additions (not in the reference) -------------------------------------
+    int dim_ = 2;                // 3 enables the 3-D extension (distance, basis, PHS Laplacian)
+    vector<int> tile_ptr_;       // tile boundaries produced by mc_order_points()
+    int lanes_per_row_ = 0;      // device layout hints, 0 = automatic
+    int tile_size_ = 0;
+    int setup_threads_ = 0;      // 0 = hardware concurrency
+
+    Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source);
+    virtual ~Grid();
+    Grid(const Grid &) = delete;
+    Grid &operator=(const Grid &) = delete;
+
+    // hot path (device)
+    void boundaryOp(std::string coarse);                                       // grid.cpp:42-51
+    void sor(SparseRowMajor *matrix, VectorXd *values, VectorXd *rhs);         // grid.cpp:104-146
+    void modify_coeff_neumann(std::string coarse);                             // grid.cpp:62-72
+    void bound_eval_neumann();                                                 // grid.cpp:73-103
+    void fix_vector_bound_coarse(VectorXd *vec);                               // grid.cpp:197-205 (host vector)
+    VectorXd residual();                                                       // grid.cpp:147-151
+    double residual_ratio();  // ||residual()||_1 / ||source_||_1 without the host round trip
+
+    // setup (host)
+    void setBCFlag(int boundary, std::string type, vector<double> boundValue);  // grid.cpp:33-40
+    void setNeumannFlag();                                                      // grid.cpp:52-60
+    void build_laplacian();                                                     // grid.cpp:549-663
+    void push_inhomog_to_rhs();                                                 // grid.cpp:664-685
+    void build_normal_vecs(const char *filename, std::string geomtype);         // grid.cpp:442-518
+    void build_deriv_normal_bound();                                            // grid.cpp:520-548
+    void rcm_order_points();                                                    // grid.cpp:713-776
+    // MI355X ordering: spatial tiles (kd-tree leaves of <= tile_points points),
+    // tiles coloured so that coupled tiles never share a colour, points coloured
+    // inside each tile; storage order = tile colour, tile, point colour.  The
+    // sequential SOR of the reference in THIS order is what the GPU executes in
+    // parallel (few phases / levels).  Use instead of rcm_order_points().
+    void mc_order_points(int tile_points = 512);
+    void apply_order(const vector<int> &order);  // new index i <- old point order[i] (grid.cpp:744-774)
+    // Synthetic throughput operator (not in the reference): kNN-graph Laplacian with
+    // inverse-square-distance weights on the reference's stencil pattern
+    // (stencilSize nearest neighbours incl. the point itself), a_ii = -sum_j a_ij.
+    // Same sparsity/bytes as the RBF-FD Laplacian, no dense solve per point, so
+    // 1e7-point clouds can be set up in seconds for bench.py.
+    void build_graph_laplacian();
+
+    vector<Point> pointIDs_to_vector(const vector<int> &pointIDs);
+    vector<int> kNearestNeighbors(Point point, bool neumannFlag, bool pointBCFlag, int k);  // grid.cpp:216-260
+    vector<int> kNearestNeighbors(int pointNumber, bool neumannFlag, int k);                // grid.cpp:213-215
+    std::tuple<MatrixXd, vector<int>, vector<Point>> buildCoeffMatrix(Point point, bool neumann, bool pointBCFlag, int polyDeg);
+    std::tuple<MatrixXd, vector<int>, vector<Point>> buildCoeffMatrix(int pointNum, bool neumann, int polyDeg);
+    std::pair<VectorXd, vector<int>> laplaceWeights(int pointID);                  // grid.cpp:381-424
+    std::pair<VectorXd, vector<int>> derivx_weights(int pointID);                  // grid.cpp:304-342
+    std::pair<VectorXd, vector<int>> derivy_weights(int pointID);                  // grid.cpp:343-380
+    std::pair<VectorXd, vector<int>> derivz_weights(int pointID);                  // 3-D extension
+    std::pair<VectorXd, vector<int>> pointInterpWeights(Point point, int polyDeg); // grid.cpp:687-712
+
+    int getSize();
+    int getStencilSize();
+    int getPolyDeg();
+
+    // ---- device coherence (used by Multigrid) -------------------------------------
+    mmg_level *device();      // creates the device level on first use
+    void sync_to_device();    // uploads values_/source_ if the host copy is newer
+    void mark_values_on_device();
+    void mark_source_on_device();
+    void invalidate_device();
+    static int polyTerms(int polyDeg, int dim);
+    static int stencilSizeFor(int polyDeg, int dim);
+
+protected:
+    enum Op { OP_LAPLACE, OP_DX, OP_DY, OP_DZ, OP_INTERP };
+    std::pair<VectorXd, vector<int>> stencil_weights(Point point, bool neumann, bool pointBCFlag, int polyDeg, Op op);
+    void ensure_knn();
+    int threads() const;
+    mmgh::CellGrid knn_;
+    mmg_level *dev_ = nullptr;
+};
+#endif

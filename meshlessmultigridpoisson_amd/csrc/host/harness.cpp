@@ -1,0 +1,353 @@
+// harness.cpp -- C entry points over the host classes, for tests/ and bench.py
+// (ctypes).  It restates the *sequence of calls* of the reference's drivers
+// (testing_functions.cpp:68-159 genGmshGridDirichlet, :161-284
+// genGmshGridNeumann, :328-343 run_mg_sim, :431-442 testGmshSingleGrid) on
+// clouds handed in by the caller; the drivers themselves (file naming, txt
+// dumps, parameter sweeps) are out of scope.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/mmgp.h"
+#include "fileReadingFunctions.h"
+#include "multigrid.h"
+
+#define PI_REF 3.141592653589793238462643383279  // testing_functions.hpp:9
+
+namespace {
+thread_local std::string g_herr;
+template <class F>
+int guard(F f)
+{
+    try { f(); return 0; }
+    catch (const std::exception &e) { g_herr = e.what(); return 1; }
+}
+
+std::vector<Point> to_points(const double *xyz, int n)
+{
+    std::vector<Point> p((size_t)n);
+    for (int i = 0; i < n; ++i) p[(size_t)i] = Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    return p;
+}
+
+bool on_box_boundary(const Point &p, int dim)
+{
+    const double x = std::get<0>(p), y = std::get<1>(p), z = std::get<2>(p);
+    if (x == 0 || x == 1 || y == 0 || y == 1) return true;  // testing_functions.cpp:86
+    return dim >= 3 && (z == 0 || z == 1);
+}
+
+void order_points(Grid *g, int ordering, int tile_points)
+{
+    if (ordering == 0) g->rcm_order_points();
+    else if (ordering == 1) g->mc_order_points(tile_points);
+}
+
+GridProperties make_props(int polyDeg, int dim, double omega, int iters)
+{
+    GridProperties p;  // testing_functions.cpp:372-380
+    p.iters = iters;
+    p.polyDeg = polyDeg;
+    p.omega = omega;
+    p.rbfExp = 3;
+    p.stencilSize = Grid::stencilSizeFor(polyDeg, dim);
+    return p;
+}
+
+// testing_functions.cpp:68-159, geomtype "square" (k1,k2 manufactured source, zero or given Dirichlet data)
+Grid *gen_dirichlet(const double *xyz, int n, int dim, GridProperties props, int k1, int k2, int ordering,
+                    int tile_points, const double *bval_abc)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n);
+    std::vector<int> bPts;
+    std::vector<double> bValues;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]), y = std::get<1>(pts[(size_t)i]), z = std::get<2>(pts[(size_t)i]);
+        double s = -(k1 * k1 + k2 * k2) * PI_REF * PI_REF * std::sin(k1 * PI_REF * x) * std::sin(k2 * PI_REF * y);
+        if (dim >= 3) s = -(k1 * k1 + 2 * k2 * k2) * PI_REF * PI_REF * std::sin(k1 * PI_REF * x) * std::sin(k2 * PI_REF * y) * std::sin(k2 * PI_REF * z);
+        source(i) = s;
+        if (on_box_boundary(pts[(size_t)i], dim)) {
+            bPts.push_back(i);
+            bValues.push_back(bval_abc ? bval_abc[0] + bval_abc[1] * x + bval_abc[2] * y : 0.0);
+        }
+    }
+    Boundary b;
+    b.bcPoints = bPts;
+    b.type = 1;
+    b.values = bValues;
+    Grid *g = new Grid(pts, std::vector<Boundary>(1, b), props, source);
+    g->dim_ = dim;
+    g->implicitFlag_ = false;
+    g->setBCFlag(0, std::string("dirichlet"), bValues);
+    order_points(g, ordering, tile_points);
+    return g;
+}
+
+// testing_functions.cpp:161-284, geomtype "square"
+Grid *gen_neumann(const double *xyz, int n, int dim, GridProperties props, int k1, int k2, int ordering,
+                  int tile_points, bool coarse)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n + 1);
+    std::vector<int> bPts;
+    std::vector<double> bValues;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]), y = std::get<1>(pts[(size_t)i]);
+        source(i) = -(k1 * k1 + k2 * k2) * PI_REF * PI_REF * std::cos(k1 * PI_REF * x) * std::cos(k2 * PI_REF * y);
+        if (on_box_boundary(pts[(size_t)i], dim)) { bPts.push_back(i); bValues.push_back(0.0); }
+    }
+    source(n) = 0;
+    Boundary b;
+    b.bcPoints = bPts;
+    b.type = 2;
+    b.values = bValues;
+    Grid *g = new Grid(pts, std::vector<Boundary>(1, b), props, source);
+    g->dim_ = dim;
+    g->implicitFlag_ = true;
+    g->setBCFlag(0, std::string("neumann"), bValues);
+    g->build_normal_vecs("", "square");
+    order_points(g, ordering, tile_points);
+    g->build_deriv_normal_bound();
+    g->build_laplacian();
+    g->modify_coeff_neumann(coarse ? "coarse" : "fine");
+    g->push_inhomog_to_rhs();
+    return g;
+}
+}  // namespace
+
+extern "C" {
+
+const char *mmgh_last_error() { return g_herr.c_str(); }
+
+// ---- Multigrid scenarios -------------------------------------------------------------------
+// levels coarse -> fine; npts[l] points each, concatenated in xyz.
+// ordering: 0 rcm_order_points (reference), 1 mc_order_points (MI355X), 2 as given.
+void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, const int *polydeg, int dim, int neumann,
+                            int k1, int k2, int ordering, int tile_points, double omega, int iters, int frac_step,
+                            const double *bval_abc, int lanes_per_row)
+{
+    Multigrid *mg = nullptr;
+    const int rc = guard([&]() {
+        mg = frac_step ? new FractionalStepMultigrid() : new Multigrid();
+        mg->printResiduals_ = false;
+        size_t off = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            GridProperties props = make_props(polydeg[l], dim, omega, iters);
+            Grid *g;
+            if (neumann) g = gen_neumann(xyz + 3 * off, npts[l], dim, props, k1, k2, ordering, tile_points, l != nlevels - 1);
+            else {
+                g = gen_dirichlet(xyz + 3 * off, npts[l], dim, props, k1, k2, ordering, tile_points, bval_abc);
+                g->build_laplacian();
+            }
+            g->lanes_per_row_ = lanes_per_row;
+            mg->addGrid(g);
+            off += (size_t)npts[l];
+        }
+        mg->buildMatrices();
+    });
+    if (rc) { delete mg; return nullptr; }
+    return mg;
+}
+
+void mmgh_mg_destroy(void *h) { delete static_cast<Multigrid *>(h); }
+int mmgh_mg_nlevels(void *h) { return (int)static_cast<Multigrid *>(h)->grids_.size(); }
+void *mmgh_mg_grid(void *h, int l) { return static_cast<Multigrid *>(h)->grids_.at((size_t)l).second; }
+
+int mmgh_mg_vcycle(void *h, double *resid_before)
+{
+    return guard([&]() {
+        Multigrid *mg = static_cast<Multigrid *>(h);
+        const size_t before = mg->residuals_.size();
+        mg->vCycle();
+        *resid_before = mg->residuals_.size() > before ? mg->residuals_.back() : -1.0;
+    });
+}
+int mmgh_mg_vcycles(void *h, int n, double *resid, float *ms)
+{
+    return guard([&]() {
+        Multigrid *mg = static_cast<Multigrid *>(h);
+        const size_t before = mg->residuals_.size();
+        mg->vCycles(n, ms);
+        for (size_t k = before; k < mg->residuals_.size() && (int)(k - before) < n; ++k) resid[k - before] = mg->residuals_[k];
+    });
+}
+int mmgh_mg_residual(void *h, double *r) { return guard([&]() { *r = static_cast<Multigrid *>(h)->residual(); }); }
+
+// transfer matrices in the reference's column-major storage: which = 0 restriction, 1 prolongation
+int mmgh_mg_transfer_shape(void *h, int which, int l, int *rows, int *cols, int *nnz)
+{
+    Multigrid *mg = static_cast<Multigrid *>(h);
+    mmgh::Sparse *m = which == 0 ? mg->restrictionMatrices_.at((size_t)l) : mg->prolongMatrices_.at((size_t)l);
+    if (!m) return 1;
+    *rows = m->rows();
+    *cols = m->cols();
+    *nnz = m->nonZeros();
+    return 0;
+}
+int mmgh_mg_transfer_get(void *h, int which, int l, int *colptr, int *rowidx, double *val)
+{
+    Multigrid *mg = static_cast<Multigrid *>(h);
+    mmgh::Sparse *m = which == 0 ? mg->restrictionMatrices_.at((size_t)l) : mg->prolongMatrices_.at((size_t)l);
+    if (!m) return 1;
+    std::memcpy(colptr, m->outerIndexPtr(), sizeof(int) * ((size_t)m->cols() + 1));
+    std::memcpy(rowidx, m->innerIndexPtr(), sizeof(int) * (size_t)m->nonZeros());
+    std::memcpy(val, m->valuePtr(), sizeof(double) * (size_t)m->nonZeros());
+    return 0;
+}
+
+// ---- single Grid ---------------------------------------------------------------------------
+// kind: 0 Dirichlet RBF-FD Laplacian, 1 Neumann RBF-FD Laplacian, 2 Dirichlet graph-Laplacian surrogate
+void *mmgh_grid_create_square(int n, const double *xyz, int polydeg, int dim, int kind, int k1, int k2, int ordering,
+                              int tile_points, double omega, int iters, int lanes_per_row, int stencil_override)
+{
+    Grid *g = nullptr;
+    const int rc = guard([&]() {
+        GridProperties props = make_props(polydeg, dim, omega, iters);
+        if (stencil_override > 0) props.stencilSize = stencil_override;
+        if (kind == 1) g = gen_neumann(xyz, n, dim, props, k1, k2, ordering, tile_points, false);
+        else {
+            g = gen_dirichlet(xyz, n, dim, props, k1, k2, ordering, tile_points, nullptr);
+            if (kind == 0) g->build_laplacian();
+            else g->build_graph_laplacian();
+        }
+        g->lanes_per_row_ = lanes_per_row;
+    });
+    if (rc) { delete g; return nullptr; }
+    return g;
+}
+void mmgh_grid_destroy(void *g) { delete static_cast<Grid *>(g); }
+
+void mmgh_grid_sizes(void *gp, int *out)  // n, a_size, nnz, neumann, n_boundaries, n_bpts, n_tiles, stencil
+{
+    Grid *g = static_cast<Grid *>(gp);
+    out[0] = g->laplaceMatSize_;
+    out[1] = g->laplaceMat_->rows();
+    out[2] = g->laplaceMat_->nonZeros();
+    out[3] = g->neumannFlag_ ? 1 : 0;
+    out[4] = (int)g->boundaries_.size();
+    int nb = 0;
+    for (auto &b : g->boundaries_) nb += (int)b.bcPoints.size();
+    out[5] = nb;
+    out[6] = g->tile_ptr_.empty() ? 0 : (int)g->tile_ptr_.size() - 1;
+    out[7] = g->properties_.stencilSize;
+}
+void mmgh_grid_get_csr(void *gp, int *rowptr, int *col, double *val)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    std::memcpy(rowptr, g->laplaceMat_->outerIndexPtr(), sizeof(int) * ((size_t)g->laplaceMat_->rows() + 1));
+    std::memcpy(col, g->laplaceMat_->innerIndexPtr(), sizeof(int) * (size_t)g->laplaceMat_->nonZeros());
+    std::memcpy(val, g->laplaceMat_->valuePtr(), sizeof(double) * (size_t)g->laplaceMat_->nonZeros());
+}
+void mmgh_grid_get_points(void *gp, double *xyz, int *bcflags)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    for (size_t i = 0; i < g->points_.size(); ++i) {
+        xyz[3 * i] = std::get<0>(g->points_[i]);
+        xyz[3 * i + 1] = std::get<1>(g->points_[i]);
+        xyz[3 * i + 2] = std::get<2>(g->points_[i]);
+        bcflags[i] = g->bcFlags_[i];
+    }
+}
+void mmgh_grid_get_boundaries(void *gp, int *btype, int *bptr, int *bpts, double *bvals)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    int k = 0;
+    bptr[0] = 0;
+    for (size_t b = 0; b < g->boundaries_.size(); ++b) {
+        btype[b] = g->boundaries_[b].type;
+        for (size_t j = 0; j < g->boundaries_[b].bcPoints.size(); ++j) {
+            bpts[k] = g->boundaries_[b].bcPoints[j];
+            bvals[k] = j < g->boundaries_[b].values.size() ? g->boundaries_[b].values[j] : 0.0;
+            ++k;
+        }
+        bptr[b + 1] = k;
+    }
+}
+void mmgh_grid_get_tile_ptr(void *gp, int *tp)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    std::memcpy(tp, g->tile_ptr_.data(), sizeof(int) * g->tile_ptr_.size());
+}
+int mmgh_grid_get_values(void *gp, double *x) { return guard([&]() { Grid *g = static_cast<Grid *>(gp); std::memcpy(x, g->values_->data(), sizeof(double) * (size_t)g->values_->rows()); }); }
+int mmgh_grid_get_source(void *gp, double *b) { return guard([&]() { Grid *g = static_cast<Grid *>(gp); std::memcpy(b, g->source_.data(), sizeof(double) * (size_t)g->source_.rows()); }); }
+void mmgh_grid_set_values(void *gp, const double *x)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    std::vector<double> &v = g->values_->host_mut();
+    std::memcpy(v.data(), x, sizeof(double) * v.size());
+}
+void mmgh_grid_set_source(void *gp, const double *b)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    std::vector<double> &v = g->source_.host_mut();
+    std::memcpy(v.data(), b, sizeof(double) * v.size());
+}
+void mmgh_grid_set_value_at(void *gp, int i, double v) { static_cast<Grid *>(gp)->values_->coeffRef(i) = v; }
+double mmgh_grid_value_at(void *gp, int i) { return static_cast<Grid *>(gp)->values_->coeff(i); }
+
+int mmgh_grid_sor(void *gp) { return guard([&]() { Grid *g = static_cast<Grid *>(gp); g->sor(g->laplaceMat_, g->values_, &g->source_); }); }
+int mmgh_grid_boundary_op(void *gp, int coarse) { return guard([&]() { static_cast<Grid *>(gp)->boundaryOp(coarse ? "coarse" : "fine"); }); }
+int mmgh_grid_bound_eval_neumann(void *gp) { return guard([&]() { static_cast<Grid *>(gp)->bound_eval_neumann(); }); }
+int mmgh_grid_modify_coeff_neumann(void *gp, int coarse) { return guard([&]() { static_cast<Grid *>(gp)->modify_coeff_neumann(coarse ? "coarse" : "fine"); }); }
+int mmgh_grid_residual(void *gp, double *r)
+{
+    return guard([&]() {
+        mmgh::Vec v = static_cast<Grid *>(gp)->residual();
+        std::memcpy(r, v.data(), sizeof(double) * (size_t)v.rows());
+    });
+}
+int mmgh_grid_residual_ratio(void *gp, double *r) { return guard([&]() { *r = static_cast<Grid *>(gp)->residual_ratio(); }); }
+// device handle of the level (creates it): for bench.py's event-timed sweeps through the C-ABI
+void *mmgh_grid_device(void *gp)
+{
+    void *d = nullptr;
+    if (guard([&]() { Grid *g = static_cast<Grid *>(gp); g->sync_to_device(); d = g->device(); })) return nullptr;
+    return d;
+}
+int mmgh_grid_sor_wrong_args(void *gp)  // error behaviour check: foreign vectors are rejected loudly
+{
+    return guard([&]() { Grid *g = static_cast<Grid *>(gp); mmgh::Vec other(g->values_->rows()); g->sor(g->laplaceMat_, &other, &g->source_); });
+}
+
+// ---- leaf functions & file formats ---------------------------------------------------------
+double mmgh_distance(const double *p, const double *q) { return distance(Point(p[0], p[1], p[2]), Point(q[0], q[1], q[2])); }
+void mmgh_shifting_scaling(const double *xyz, int n, const double *ev, double *out)
+{
+    auto sp = shifting_scaling(to_points(xyz, n), Point(ev[0], ev[1], ev[2]));
+    for (size_t i = 0; i < sp.size(); ++i) { out[3 * i] = std::get<0>(sp[i]); out[3 * i + 1] = std::get<1>(sp[i]); out[3 * i + 2] = std::get<2>(sp[i]); }
+}
+int mmgh_rcm(const int *ptr, const int *idx, int n, int *order)
+{
+    std::vector<std::vector<int>> adj((size_t)n);
+    for (int i = 0; i < n; ++i) adj[(size_t)i].assign(idx + ptr[i], idx + ptr[i + 1]);
+    std::vector<int> ord((size_t)n);
+    reverse_cuthill_mckee_ordering(adj, ord);
+    for (size_t i = 0; i < ord.size(); ++i) order[i] = ord[i];
+    return (int)ord.size();
+}
+int mmgh_points_from_msh(const char *fname, double *xyz, int cap, int txt)
+{
+    auto pts = txt ? pointsFromTxts(fname) : pointsFromMshFile(fname);
+    for (size_t i = 0; i < pts.size() && (int)i < cap; ++i) { xyz[3 * i] = std::get<0>(pts[i]); xyz[3 * i + 1] = std::get<1>(pts[i]); xyz[3 * i + 2] = std::get<2>(pts[i]); }
+    return (int)pts.size();
+}
+void mmgh_bound_pts_conn(const char *fname, const int *bcflags, int n, int *conn)
+{
+    auto c = boundPtsConnFromMsh(fname, std::vector<int>(bcflags, bcflags + n));
+    for (int i = 0; i < n; ++i) { conn[2 * i] = c[(size_t)i].first; conn[2 * i + 1] = c[(size_t)i].second; }
+}
+void mmgh_write_vector_txt(const double *v, int n, const char *fname) { writeVectorToTxt(std::vector<double>(v, v + n), fname); }
+int mmgh_order_from_txt(const char *fname, int nv) { return (int)orderFromTxt(fname, nv).size(); }
+int mmgh_write_msh(const char *fname, const double *xyz, int n) { return writePointsToMshFile(fname, to_points(xyz, n)) ? 0 : 1; }
+// k nearest neighbours of point `pid` with the reference's exclusion rule
+int mmgh_grid_knn(void *gp, int pid, int k, int *out)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    auto nb = g->kNearestNeighbors(pid, g->neumannFlag_, k);
+    for (size_t i = 0; i < nb.size(); ++i) out[i] = nb[i];
+    return (int)nb.size();
+}
+
+}  // extern "C"

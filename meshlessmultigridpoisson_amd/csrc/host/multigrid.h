@@ -1,0 +1,56 @@
+// multigrid.h -- host-side mirror of the reference's `Multigrid`
+// (MeshlessPoisson/multigrid.h:4-23) and, with fracStep_ = true, of
+// `FractionalStepMultigrid` (FracStepMultigrid.hpp).  Same public members; the
+// V-cycle itself runs device-resident through mmg_vcycle (one host sync per
+// cycle for the residual scalar).
+#ifndef MMGH_MULTIGRID_H
+#define MMGH_MULTIGRID_H
+#include "grid.h"
+
+struct mmg_transfer;
+struct mmg_hierarchy;
+
+class Multigrid {
+public:
+    typedef mmgh::Sparse SparseColMajor;  // constructed with row_major = false
+
+    vector<std::pair<int, Grid *>> grids_;  // sorted by size: [0] coarsest
+    vector<int> sorGridIters_;
+    vector<SparseColMajor *> restrictionMatrices_;
+    vector<SparseColMajor *> prolongMatrices_;
+    vector<double> residuals_;
+    bool fracStep_ = false;      // FracStepMultigrid.cpp semantics (:23, :64-67, no print)
+    bool printResiduals_ = true; // multigrid.cpp:69 prints every cycle
+
+    Multigrid();
+    virtual ~Multigrid();
+    Multigrid(const Multigrid &) = delete;
+    Multigrid &operator=(const Multigrid &) = delete;
+
+    void sortGridsBySize();                                               // multigrid.cpp:120-122
+    SparseColMajor *buildInterpMatrix(Grid *baseGrid, Grid *targetGrid);  // multigrid.cpp:17-33
+    void buildRestrictionMatrices();                                      // multigrid.cpp:42-48
+    void buildProlongMatrices();                                          // multigrid.cpp:35-41
+    void addGrid(Grid *grid);                                             // multigrid.cpp:116-119
+    void buildMatrices();                                                 // multigrid.cpp:49-60
+    void vCycle();                                                        // multigrid.cpp:62-110
+    double residual();                                                    // multigrid.cpp:112-115
+    // not in the reference: n cycles back to back without per-cycle host work
+    void vCycles(int n, float *device_ms = nullptr);
+
+protected:
+    void ensure_device();
+    void sync_all();
+    void mark_all();
+    void drop_device();
+    vector<mmg_transfer *> devR_, devP_;
+    mmg_hierarchy *devH_ = nullptr;
+};
+
+// FracStepMultigrid.hpp: identical surface over FractionalStepGrid*
+class FractionalStepMultigrid : public Multigrid {
+public:
+    FractionalStepMultigrid() { fracStep_ = true; printResiduals_ = false; }
+    void solveLoop() {}  // FracStepMultigrid.cpp:113-115 (empty in the reference)
+};
+#endif

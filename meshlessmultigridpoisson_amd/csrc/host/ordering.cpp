@@ -1,0 +1,214 @@
+// ordering.cpp -- Grid::mc_order_points: the MI355X point ordering.
+//
+// The reference reorders points with a BFS/RCM pass (grid.cpp:713-776) and then
+// relaxes them sequentially in storage order.  Point order is therefore a free
+// input of the method.  This ordering is chosen so that the SAME sequential
+// Gauss-Seidel sweep decomposes into few parallel stages on the GPU:
+//   1. kd-tree leaves of <= tile_points points  -> spatial tiles (LDS working sets)
+//   2. greedy colouring of the tile graph        -> tiles of one colour never couple
+//   3. greedy colouring of the points of a tile  -> same-colour rows never couple
+//   storage order = (tile colour, tile, point colour, kd order); boundary points
+//   (never relaxed) go to the end of their tile.
+// "Couple" = a_ij != 0 or a_ji != 0 in the matrix build_laplacian() will create:
+// the kNN stencil, plus the fill of the implicit Neumann elimination.
+// libmmgp derives its schedule from the actual matrix, so a mismatch between
+// this prediction and the matrix can cost performance, never correctness.
+#include <algorithm>
+#include <atomic>
+#include <numeric>
+#include <thread>
+
+#include "grid.h"
+
+namespace {
+
+double comp(const Point &p, int a) { return a == 0 ? std::get<0>(p) : (a == 1 ? std::get<1>(p) : std::get<2>(p)); }
+
+struct KdSplit {
+    const std::vector<Point> &pts;
+    int dim, leaf;
+    std::vector<int> &idx;
+    std::vector<int> bounds;  // leaf start offsets, unsorted (threads append under lock-free scheme via per-call vectors)
+
+    void run(int lo, int hi, std::vector<int> &out_bounds, int depth)
+    {
+        const int n = hi - lo;
+        if (n <= leaf) { out_bounds.push_back(lo); return; }
+        const int nl = (n + leaf - 1) / leaf;
+        const int left_leaves = nl / 2;
+        const int mid = lo + (int)((long long)n * left_leaves / nl);
+        double mn[3], mx[3];
+        for (int a = 0; a < dim; ++a) { mn[a] = 1e300; mx[a] = -1e300; }
+        for (int k = lo; k < hi; ++k)
+            for (int a = 0; a < dim; ++a) {
+                const double v = comp(pts[(size_t)idx[(size_t)k]], a);
+                mn[a] = std::min(mn[a], v);
+                mx[a] = std::max(mx[a], v);
+            }
+        int ax = 0;
+        for (int a = 1; a < dim; ++a)
+            if (mx[a] - mn[a] > mx[ax] - mn[ax]) ax = a;
+        std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int x, int y) {
+            const double vx = comp(pts[(size_t)x], ax), vy = comp(pts[(size_t)y], ax);
+            return vx < vy || (vx == vy && x < y);
+        });
+        if (depth < 4 && n > 200000) {
+            std::vector<int> right;
+            std::thread t([&]() { run(mid, hi, right, depth + 1); });
+            run(lo, mid, out_bounds, depth + 1);
+            t.join();
+            out_bounds.insert(out_bounds.end(), right.begin(), right.end());
+        } else {
+            run(lo, mid, out_bounds, depth + 1);
+            run(mid, hi, out_bounds, depth + 1);
+        }
+    }
+};
+
+template <class F>
+void par_for(int n, int nth, F f)
+{
+    if (nth <= 1 || n < 256) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int b = next.fetch_add(64);
+                if (b >= n) break;
+                for (int i = b; i < std::min(n, b + 64); ++i) f(i);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+void Grid::mc_order_points(int tile_points)
+{
+    const int n = (int)points_.size();
+    if (tile_points < 8) tile_points = 8;
+    ensure_knn();
+    const int nth = threads();
+
+    // ---- predicted coupling graph (same construction as rcm_order_points) -------
+    vector<vector<int>> adj((size_t)n);
+    par_for(n, nth, [&](int i) {
+        adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
+    });
+    if (neumannFlag_ && implicitFlag_) {
+        for (int i = 0; i < n; ++i) {
+            if (bcFlags_[(size_t)i] != 0) continue;
+            const size_t base = adj[(size_t)i].size();
+            for (size_t j = 0; j < base; ++j) {
+                const int a = adj[(size_t)i][j];
+                if (bcFlags_[(size_t)a] != 2) continue;
+                for (int k : adj[(size_t)a])
+                    if (std::find(adj[(size_t)i].begin(), adj[(size_t)i].end(), k) == adj[(size_t)i].end()) adj[(size_t)i].push_back(k);
+            }
+        }
+    }
+
+    // ---- 1. spatial tiles ---------------------------------------------------------
+    vector<int> idx((size_t)n);
+    std::iota(idx.begin(), idx.end(), 0);
+    vector<int> bounds;
+    KdSplit kd{points_, dim_, tile_points, idx, {}};
+    kd.run(0, n, bounds, 0);
+    std::sort(bounds.begin(), bounds.end());
+    bounds.push_back(n);
+    const int nt = (int)bounds.size() - 1;
+    vector<int> tile_of((size_t)n), pos_in((size_t)n);
+    for (int t = 0; t < nt; ++t)
+        for (int k = bounds[(size_t)t]; k < bounds[(size_t)t + 1]; ++k) {
+            tile_of[(size_t)idx[(size_t)k]] = t;
+            pos_in[(size_t)idx[(size_t)k]] = k - bounds[(size_t)t];
+        }
+
+    // ---- 2. tile graph + colours (only relaxed rows create dependencies) ------------
+    vector<vector<int>> tnb((size_t)nt);
+    {
+        vector<vector<int>> fwd((size_t)nt);
+        par_for(nt, nth, [&](int t) {
+            vector<int> &v = fwd[(size_t)t];
+            for (int k = bounds[(size_t)t]; k < bounds[(size_t)t + 1]; ++k) {
+                const int i = idx[(size_t)k];
+                if (bcFlags_[(size_t)i] != 0) continue;
+                for (int j : adj[(size_t)i]) {
+                    if (bcFlags_[(size_t)j] != 0) continue;
+                    const int tj = tile_of[(size_t)j];
+                    if (tj != t && (v.empty() || v.back() != tj)) v.push_back(tj);
+                }
+            }
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        });
+        for (int t = 0; t < nt; ++t)
+            for (int u : fwd[(size_t)t]) { tnb[(size_t)t].push_back(u); tnb[(size_t)u].push_back(t); }
+    }
+    vector<int> tcol((size_t)nt, -1);
+    {
+        vector<int> mark;
+        for (int t = 0; t < nt; ++t) {
+            auto &v = tnb[(size_t)t];
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            mark.assign(v.size() + 2, 0);
+            for (int u : v)
+                if (tcol[(size_t)u] >= 0 && tcol[(size_t)u] < (int)mark.size()) mark[(size_t)tcol[(size_t)u]] = 1;
+            int c = 0;
+            while (mark[(size_t)c]) ++c;
+            tcol[(size_t)t] = c;
+        }
+    }
+
+    // ---- 3. point colours inside each tile --------------------------------------------
+    vector<int> pcol((size_t)n, 0);
+    par_for(nt, nth, [&](int t) {
+        const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
+        vector<vector<int>> ladj((size_t)m);
+        for (int k = b; k < e; ++k) {
+            const int i = idx[(size_t)k];
+            if (bcFlags_[(size_t)i] != 0) continue;
+            for (int j : adj[(size_t)i]) {
+                if (j == i || bcFlags_[(size_t)j] != 0 || tile_of[(size_t)j] != t) continue;
+                ladj[(size_t)(k - b)].push_back(pos_in[(size_t)j]);
+                ladj[(size_t)pos_in[(size_t)j]].push_back(k - b);
+            }
+        }
+        vector<int> col((size_t)m, -1), mark;
+        for (int k = 0; k < m; ++k) {
+            const int i = idx[(size_t)(b + k)];
+            if (bcFlags_[(size_t)i] != 0) continue;
+            mark.assign(ladj[(size_t)k].size() + 2, 0);
+            for (int u : ladj[(size_t)k])
+                if (col[(size_t)u] >= 0 && col[(size_t)u] < (int)mark.size()) mark[(size_t)col[(size_t)u]] = 1;
+            int c = 0;
+            while (mark[(size_t)c]) ++c;
+            col[(size_t)k] = c;
+            pcol[(size_t)i] = c;
+        }
+    });
+
+    // ---- storage order --------------------------------------------------------------------
+    vector<int> torder((size_t)nt);
+    std::iota(torder.begin(), torder.end(), 0);
+    std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
+    vector<int> order;
+    order.reserve((size_t)n);
+    vector<int> tptr(1, 0);
+    for (int t : torder) {
+        const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1];
+        vector<int> loc(idx.begin() + b, idx.begin() + e);
+        std::stable_sort(loc.begin(), loc.end(), [&](int x, int y) {
+            const bool bx = bcFlags_[(size_t)x] != 0, by = bcFlags_[(size_t)y] != 0;
+            if (bx != by) return by;  // interior first
+            if (bx) return false;
+            return pcol[(size_t)x] < pcol[(size_t)y];
+        });
+        order.insert(order.end(), loc.begin(), loc.end());
+        tptr.push_back((int)order.size());
+    }
+    apply_order(order);
+    tile_ptr_ = tptr;
+}

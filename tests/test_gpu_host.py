@@ -1,0 +1,108 @@
+"""GPU tests of the drop-in layer: the host C++ `Grid` / `Multigrid` classes
+(csrc/host, mirror of the reference's grid.h / multigrid.h) driving the HIP path,
+compared with the CPU oracle run on the matrices those classes built.
+Tolerances as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+FLOOR = 2e-13
+
+
+@pytest.fixture(scope="module")
+def host():
+    from meshlessmultigridpoisson_amd import _capi, _host
+    assert _capi.device_count() >= 1, "no HIP device visible: libmmgp has no CPU fallback"
+    return _host
+
+
+@pytest.mark.parametrize("ordering", ["rcm", "mc"])
+@pytest.mark.parametrize("neumann", [False, True])
+def test_run_mg_sim_sequence_matches_oracle(host, ordering, neumann):
+    """testing_functions.cpp:328-343 (run_mg_sim): factories -> addGrid -> buildMatrices ->
+    vCycle loop; residuals_ must follow the oracle's history on the same hierarchy."""
+    clouds = [host.square_cloud(n, seed=12345 + i) for i, n in enumerate([13, 25, 49])]
+    polys = [3, 3, 3] if neumann else [3, 3, 4]
+    mg = host.Multigrid(clouds, polys, neumann=neumann,
+                        ordering=host.ORDER_RCM if ordering == "rcm" else host.ORDER_MC, tile_points=128)
+    om = mg.oracle()
+    for k in range(12):
+        ro = om.vcycle()
+        rd = mg.vcycle()
+        assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+    xo = om.levels[-1].x
+    xd = mg.grid(2).values()          # lazy download through the Vec mirror
+    assert np.abs(xd - xo).max() <= 1e-9 * np.abs(xo).max()
+    assert abs(mg.residual() - om.residual()) <= 1e-10 * om.residual() + FLOOR
+    if not neumann:                    # known-answer: manufactured sin*sin solution (testing_functions.cpp:3-33)
+        mg.vcycles(25)
+        xyz, _ = mg.grid(2).points()
+        exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
+        assert np.abs(mg.grid(2).values() - exact).sum() / len(exact) < 5e-5
+
+
+def test_single_grid_loop_and_host_mirror(host):
+    """testing_functions.cpp:431-442 (testGmshSingleGrid): boundaryOp("fine"), then
+    residual ratio / sor in a loop; plus coherence of the public values_ mirror."""
+    from meshlessmultigridpoisson_amd import _host
+    pts = host.square_cloud(33, seed=5)
+    g = host.Grid.create_square(pts, 4, kind=_host.KIND_DIRICHLET, ordering=_host.ORDER_MC, tile_points=256)
+    la = g.level_arrays()
+    o = H.oracle_level(la)
+    g.boundary_op(0)
+    o.boundary_op(0)
+    for _ in range(4):
+        assert abs(g.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio()
+        g.sor()
+        o.sor()
+    assert H.rel_err(g.values(), o.x) < 1e-12
+    r = g.residual()
+    assert np.abs(r - o.residual()).max() <= 1e-11 * np.abs(o.b).max()
+    # a host write through values_ must reach the device before the next hot call
+    host.lib().mmgh_grid_set_value_at(g.h, 100, 0.25)
+    o.x[100] = 0.25
+    g.sor()
+    o.sor()
+    assert H.rel_err(g.values(), o.x) < 1e-12
+    assert host.lib().mmgh_grid_value_at(g.h, 100) == o.x[100]
+    # error behaviour: foreign vectors are rejected loudly, not silently computed on the CPU
+    assert host.lib().mmgh_grid_sor_wrong_args(g.h) == 1
+    assert b"only (laplaceMat_" in host.lib().mmgh_last_error()
+
+
+def test_neumann_grid_ops(host):
+    from meshlessmultigridpoisson_amd import _host
+    pts = host.square_cloud(25, seed=6)
+    g = host.Grid.create_square(pts, 3, kind=_host.KIND_NEUMANN, ordering=_host.ORDER_MC, tile_points=128)
+    la = g.level_arrays()
+    o = H.oracle_level(la)
+    g.sor()
+    o.sor()
+    assert H.rel_err(g.values(), o.x) < 1e-12
+    g.modify_coeff_neumann(1)
+    o.modify_coeff_neumann(1)
+    assert np.array_equal(g.source(), o.b)
+    g.bound_eval_neumann()
+    o.bound_eval_neumann()
+    assert H.rel_err(g.values(), o.x) < 1e-12
+
+
+def test_3d_graph_level_large_tiles(host):
+    """3-D K=50 stencils (BASELINE configs[2] shape, small): parity of sweeps through
+    the host Grid + mc ordering at several device layouts."""
+    from meshlessmultigridpoisson_amd import _host
+    pts = host.box_cloud(24, 3, seed=2)
+    for tile, lanes in [(512, 4), (1024, 2), (256, 8)]:
+        g = host.Grid.create_square(pts, 3, dim=3, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC,
+                                    tile_points=tile, lanes_per_row=lanes)
+        la = g.level_arrays()
+        rng = np.random.default_rng(1)
+        b = rng.standard_normal(la["a_size"])
+        g.set_source(b)
+        la["b0"] = b
+        o = H.oracle_level(la)
+        g.sor()
+        o.sor()
+        assert H.rel_err(g.values(), o.x) < 1e-12
