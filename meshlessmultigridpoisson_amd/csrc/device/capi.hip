@@ -117,6 +117,7 @@ struct PlanGpu {
         dev.L = P.L;
         dev.n_tiles = P.n_tiles;
         dev.lds_bytes = (unsigned)P.lds_bytes();
+        dev.max_plen = P.max_plen;
         return MMG_OK;
     }
 };

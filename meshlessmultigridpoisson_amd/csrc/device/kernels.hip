@@ -22,17 +22,74 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// cross-lane add inside groups of L lanes, DPP (no LDS traffic) up to L = 16
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return v + __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 template <int L>
 __device__ __forceinline__ double row_sum(double v)
 {
-#pragma unroll
-    for (int m = L >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (L >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
+    if (L >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
+    if (L >= 8) v = dpp_add<0x141>(v);   // row_half_mirror      : other quad of the 8
+    if (L >= 16) v = dpp_add<0x140>(v);  // row_mirror           : other half of the 16
+    if (L >= 32) v += __shfl_xor(v, 16, 64);
+    if (L >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
 __device__ __forceinline__ size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+__device__ __forceinline__ size_t group_bytes_dev(int L, int nr, int plen)
+{
+    const size_t W = (size_t)nr * L;
+    return (size_t)16 * nr + al16((size_t)plen * W * 8) + al16((size_t)((plen + 3) >> 2) * W * 8);
+}
 
-template <int L, int MODE>
+// Registers of one row group in flight: MAXP entries per lane.
+template <int MAXP>
+struct GroupRegs {
+    double v[MAXP];
+    uint2 s[(MAXP + 3) / 4];
+    RowMeta m;
+    double d;
+};
+
+// Issue every global load of one group (no waits): the stream address depends on
+// nothing but the group heads, so the next group's loads fly while the current
+// group is gathered and reduced.
+template <int L, int MAXP>
+__device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int plen, int lane, GroupRegs<MAXP> &r)
+{
+    const int W = nr * L;
+    // lanes beyond W re-read lane W-1's data (always in bounds); they are masked in finish()
+    const int ln = lane < W ? lane : W - 1;
+    const double *vals = reinterpret_cast<const double *>(p + 16 * nr) + ln;
+    const uint2 *sl = reinterpret_cast<const uint2 *>(p + 16 * nr + al16((size_t)plen * W * 8)) + ln;
+    const int plen4 = (plen + 3) >> 2;
+#pragma unroll
+    for (int q4 = 0; q4 < (MAXP + 3) / 4; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
+    const int rig = ln / L;
+    r.m = reinterpret_cast<const RowMeta *>(p)[rig];
+    r.d = reinterpret_cast<const double *>(p + 8 * nr)[rig];
+}
+
+__device__ __forceinline__ unsigned slot_of(const uint2 &s, int k)
+{
+    const unsigned w = (k & 2) ? s.y : s.x;
+    return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// One wavefront per tile.  LDS: xs[n_slots] (inputs) | bs[n_own] (rhs of the own
+// range, SOR/RESID) | gh[n_groups] (group heads).
+template <int L, int MODE, int MAXP>
 __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -49,91 +106,118 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
     const TileDesc td = a.p.tiles[tile];
     const uint32_t n_own = td.n_own, n_halo = td.n_halo, n_groups = td.n_groups;
     const uint32_t n_slots = n_own + n_halo + 1;
-    uint32_t *gh = reinterpret_cast<uint32_t *>(xs + n_slots);
+    constexpr bool kUsesB = (MODE == MODE_SOR || MODE == MODE_RESID || MODE == MODE_BOUND);
+    double *bs = xs + n_slots;
+    uint32_t *gh = reinterpret_cast<uint32_t *>(bs + (kUsesB ? n_own : 0));
 
     // ---- stage inputs in LDS ------------------------------------------------
     const double *in = a.in;
-    for (uint32_t i = lane; i < n_own; i += 64) xs[i] = in[td.row0 + i];
-    const int32_t *hl = a.p.halo + td.halo_off;
-    for (uint32_t i = lane; i < n_halo; i += 64) xs[n_own + i] = in[hl[i]];
-    if (lane == 0) xs[n_slots - 1] = 0.0;
     const uint32_t *ghg = a.p.ghead + td.ghead_off;
     for (uint32_t i = lane; i < n_groups; i += 64) gh[i] = ghg[i];
+    // batches of 8 independent loads per lane: one memory latency per batch
+    for (uint32_t base = 0; base < n_own; base += 512) {
+        double tx[8], tb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            const uint32_t ii = i < n_own ? i : n_own - 1;
+            tx[k] = in[td.row0 + ii];
+            if (kUsesB) tb[k] = a.b[td.row0 + ii];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            if (i < n_own) {
+                xs[i] = tx[k];
+                if (kUsesB) bs[i] = tb[k];
+            }
+        }
+    }
+    const int32_t *hl = a.p.halo + td.halo_off;
+    for (uint32_t base = 0; base < n_halo; base += 512) {
+        int32_t ti[8];
+        double tx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            ti[k] = hl[i < n_halo ? i : n_halo - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tx[k] = in[ti[k]];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t i = base + k * 64 + lane;
+            if (i < n_halo) xs[n_own + i] = tx[k];
+        }
+    }
+    if (lane == 0) xs[n_slots - 1] = 0.0;
     double lam = 0.0;
     if (MODE == MODE_SOR || MODE == MODE_RESID)
         if (a.lambda) lam = *a.lambda;
-    __syncthreads();
 
     const unsigned char *p = a.p.stream + td.stream_off;
+    GroupRegs<MAXP> ra, rb;
+    uint32_t h_cur = n_groups ? ghg[0] : 0;  // first head straight from global: no LDS round trip
+    if (n_groups) issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+    __syncthreads();
+
     const int sub = lane & (L - 1);
-    const int rig = lane / L;  // row in group
-    double local = 0.0;        // RESID: sum |r|
+    double local = 0.0;  // RESID: sum |r|
 
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        const uint32_t h = gh[g];
-        const int nr = (int)(h & 0xffu);
-        const int plen = (int)(h >> 8);
+    auto finish = [&](const GroupRegs<MAXP> &r, int nr, int plen) {
         const int W = nr * L;
-        const RowMeta *meta = reinterpret_cast<const RowMeta *>(p);
-        const double *diag = reinterpret_cast<const double *>(p + (size_t)8 * nr);
-        const double *vals = reinterpret_cast<const double *>(p + (size_t)16 * nr);
-        const size_t vbytes = al16((size_t)plen * W * 8);
-        const unsigned char *sl = reinterpret_cast<const unsigned char *>(vals) + vbytes;
-        const int plen4 = (plen + 3) >> 2;
-        const bool active = lane < W;
-
         double acc = 0.0;
-        if (active) {
-            const uint2 *s4p = reinterpret_cast<const uint2 *>(sl) + lane;
-            const double *vp = vals + lane;
-            for (int q4 = 0; q4 < plen4; ++q4) {
-                const uint2 s4 = s4p[(size_t)q4 * W];
-                const int q = q4 * 4;
-                const unsigned s0 = s4.x & 0xffffu, s1 = s4.x >> 16, s2 = s4.y & 0xffffu, s3 = s4.y >> 16;
-                if (q + 3 < plen) {
-                    const double v0 = vp[(size_t)(q + 0) * W], v1 = vp[(size_t)(q + 1) * W];
-                    const double v2 = vp[(size_t)(q + 2) * W], v3 = vp[(size_t)(q + 3) * W];
-                    acc = fma(v0, xs[s0], acc);
-                    acc = fma(v1, xs[s1], acc);
-                    acc = fma(v2, xs[s2], acc);
-                    acc = fma(v3, xs[s3], acc);
-                } else {
-                    if (q + 0 < plen) acc = fma(vp[(size_t)(q + 0) * W], xs[s0], acc);
-                    if (q + 1 < plen) acc = fma(vp[(size_t)(q + 1) * W], xs[s1], acc);
-                    if (q + 2 < plen) acc = fma(vp[(size_t)(q + 2) * W], xs[s2], acc);
-                }
-            }
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+            const double v = (q < plen && lane < W) ? r.v[q] : 0.0;
+            acc = fma(v, xs[slot_of(r.s[q >> 2], q & 3)], acc);
         }
         acc = row_sum<L>(acc);
-
-        if (active && sub == 0) {
-            const RowMeta m = meta[rig];
+        if (lane < W && sub == 0) {
+            const RowMeta m = r.m;
             if (MODE == MODE_SOR) {
-                const double d = diag[rig];
-                double xi = a.b[m.gid] - acc;
+                double xi = bs[m.self] - acc;
                 if (m.flags & 1) xi -= lam;
-                xi *= a.omega / d;
+                xi *= a.omega / r.d;
                 xi += (1.0 - a.omega) * xs[m.self];
                 xs[m.self] = xi;
             } else if (MODE == MODE_BOUND) {
-                const double d = diag[rig];
-                const double xi = (a.b[m.gid] - acc) / d;
+                const double bi = (m.self < n_own) ? bs[m.self] : a.b[m.gid];
+                const double xi = (bi - acc) / r.d;
                 a.out[m.gid] = xi;
                 if (m.self != kNoSlot) xs[m.self] = xi;
             } else if (MODE == MODE_RESID) {
-                const double d = diag[rig];
-                double r = a.b[m.gid] - (acc + d * xs[m.self]);
-                if (m.flags & 1) r -= lam;
-                a.out[m.gid] = r;
-                local += fabs(r);
+                const double bi = (m.self < n_own) ? bs[m.self] : a.b[m.gid];
+                double rr = bi - (acc + r.d * xs[m.self]);
+                if (m.flags & 1) rr -= lam;
+                a.out[m.gid] = rr;
+                local += fabs(rr);
             } else if (MODE == MODE_SET) {
                 a.out[m.gid] = acc;
             } else {
                 a.out[m.gid] += acc;
             }
         }
-        p += (size_t)16 * nr + vbytes + al16((size_t)plen4 * W * 8);
-        if (MODE == MODE_SOR || MODE == MODE_BOUND) __syncthreads();  // order LDS write -> next group's gathers
+    };
+
+    // two groups per trip so the register sets alternate without copies
+    for (uint32_t g = 0; g < n_groups; g += 2) {
+        const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
+        const unsigned char *p1 = p + group_bytes_dev(L, nr0, pl0);
+        uint32_t h1 = 0;
+        if (g + 1 < n_groups) {
+            h1 = gh[g + 1];
+            issue_group<L, MAXP>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
+        }
+        finish(ra, nr0, pl0);
+        if (g + 1 >= n_groups) break;
+        const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
+        p = p1 + group_bytes_dev(L, nr1, pl1);
+        if (g + 2 < n_groups) {
+            h_cur = gh[g + 2];
+            issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+        }
+        finish(rb, nr1, pl1);
     }
 
     if (MODE == MODE_SOR) {
@@ -163,21 +247,32 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
     }
 }
 
-template <int L>
-hipError_t launch_L(TileMode mode, const TileArgs &a, hipStream_t s)
+template <int L, int MAXP>
+hipError_t launch_LP(TileMode mode, const TileArgs &a, hipStream_t s)
 {
-    if (a.n_list <= 0) return hipSuccess;
     const int per = (a.n_list + 7) / 8;
     const dim3 grid((unsigned)(per * 8)), block(64);
     const size_t lds = a.p.lds_bytes;
     switch (mode) {
-    case MODE_SOR: hipLaunchKernelGGL((tile_kernel<L, MODE_SOR>), grid, block, lds, s, a); break;
-    case MODE_BOUND: hipLaunchKernelGGL((tile_kernel<L, MODE_BOUND>), grid, block, lds, s, a); break;
-    case MODE_RESID: hipLaunchKernelGGL((tile_kernel<L, MODE_RESID>), grid, block, lds, s, a); break;
-    case MODE_SET: hipLaunchKernelGGL((tile_kernel<L, MODE_SET>), grid, block, lds, s, a); break;
-    case MODE_ADD: hipLaunchKernelGGL((tile_kernel<L, MODE_ADD>), grid, block, lds, s, a); break;
+    case MODE_SOR: hipLaunchKernelGGL((tile_kernel<L, MODE_SOR, MAXP>), grid, block, lds, s, a); break;
+    case MODE_BOUND: hipLaunchKernelGGL((tile_kernel<L, MODE_BOUND, MAXP>), grid, block, lds, s, a); break;
+    case MODE_RESID: hipLaunchKernelGGL((tile_kernel<L, MODE_RESID, MAXP>), grid, block, lds, s, a); break;
+    case MODE_SET: hipLaunchKernelGGL((tile_kernel<L, MODE_SET, MAXP>), grid, block, lds, s, a); break;
+    case MODE_ADD: hipLaunchKernelGGL((tile_kernel<L, MODE_ADD, MAXP>), grid, block, lds, s, a); break;
     }
     return hipGetLastError();
+}
+
+template <int L>
+hipError_t launch_L(TileMode mode, const TileArgs &a, hipStream_t s)
+{
+    if (a.n_list <= 0) return hipSuccess;
+    const int mp = a.p.max_plen;
+    if (mp <= 8) return launch_LP<L, 8>(mode, a, s);
+    if (mp <= 16) return launch_LP<L, 16>(mode, a, s);
+    if (mp <= 28) return launch_LP<L, 28>(mode, a, s);
+    if (mp <= 64) return launch_LP<L, 64>(mode, a, s);
+    return hipErrorInvalidValue;  // build_plan caps plen (kMaxPlen)
 }
 
 // ---- small kernels -------------------------------------------------------------

@@ -15,6 +15,7 @@ struct PlanDev {
     int L = 4;
     int n_tiles = 0;
     unsigned lds_bytes = 0;
+    int max_plen = 0;
 };
 
 enum TileMode {

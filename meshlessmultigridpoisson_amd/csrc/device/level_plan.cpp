@@ -5,10 +5,22 @@
 
 namespace mmg {
 
+namespace {
+// kernels keep at most 64 entries per lane in registers: widen L for long rows
+int widen_L(const CsrView &A, const int32_t *rows, int64_t n_rows, int L)
+{
+    int maxlen = 0;
+    for (int64_t k = 0; k < n_rows; ++k) maxlen = std::max(maxlen, A.rowptr[rows[k] + 1] - A.rowptr[rows[k]]);
+    while (L < 64 && (maxlen + L - 1) / L > 64) L *= 2;
+    return L;
+}
+}  // namespace
+
 std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows,
                                    bool diag, bool self, bool in_place, int mult_col, Plan *out)
 {
     std::string err;
+    L = widen_L(A, rows.data(), (int64_t)rows.size(), L);
     int tr = std::max(1, tile_rows);
     for (int attempt = 0; attempt < 16; ++attempt) {
         std::vector<int64_t> tp = uniform_tile_ptr((int64_t)rows.size(), tr);
@@ -51,6 +63,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
     for (int i = 0; i < n; ++i)
         if (d.bcflags[i] == 0) rows.push_back(i);
     std::string err;
+    L = widen_L(A, rows.data(), (int64_t)rows.size(), L);
     for (int attempt = 0; attempt < 10; ++attempt) {
         const int nt = (int)pt_tile.size() - 1;
         std::vector<int64_t> tp((size_t)nt + 1, 0);

@@ -91,7 +91,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
     for (size_t i = 0; i < tb.halo.size(); ++i) slot_of[tb.halo[i]] = (int32_t)(n_own + i);
     const size_t n_slots = (size_t)n_own + tb.halo.size() + 1;
     auto cleanup = [&]() { for (int32_t h : tb.halo) slot_of[h] = -1; };
-    if (n_slots > (size_t)kMaxSlots) {
+    if (n_slots + (size_t)n_own > (size_t)kMaxSlots) {
         tb.err = "tile-too-large: " + std::to_string(n_slots) + " LDS slots";
         cleanup();
         return;
@@ -162,6 +162,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             int plen = 0;
             for (int i = 0; i < g; ++i)
                 plen = std::max(plen, (int)((ent[rows[g0 + i]].size() + L - 1) / L));
+            if (plen > 64) { tb.err = "row too long for lanes_per_row (more than 64 entries per lane)"; return; }
             const size_t W = (size_t)g * L;
             const size_t plen4 = ((size_t)plen + 3) / 4;
             const size_t base = tb.blob.size();
@@ -270,6 +271,8 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         gh_sz += tb[t].ghead.size();
         P.max_slots = std::max<int>(P.max_slots, (int)(d.n_own + d.n_halo + 1));
         P.max_groups = std::max<int>(P.max_groups, (int)d.n_groups);
+        P.max_own = std::max<int>(P.max_own, (int)d.n_own);
+        for (uint32_t h : tb[t].ghead) P.max_plen = std::max<int>(P.max_plen, (int)(h >> 8));
         P.n_nnz += tb[t].nnz;
     }
     P.n_rows = s.n_rows;

@@ -58,7 +58,7 @@ struct RowMeta {
 static_assert(sizeof(RowMeta) == 8, "RowMeta layout");
 
 constexpr uint16_t kNoSlot = 0xFFFF;
-constexpr int kMaxSlots = 7936;  // slots*8 B + group heads must fit 64 KiB of LDS
+constexpr int kMaxSlots = 7680;  // (slots + own rhs) * 8 B + group heads must fit 64 KiB of LDS
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -81,11 +81,13 @@ struct Plan {
     std::vector<int32_t> phase_tiles;  // tiles ordered by phase
     int max_slots = 0;                 // max over tiles of n_own + n_halo + 1
     int max_groups = 0;                // max groups of one tile
+    int max_own = 0;                   // max own range of one tile (b is staged next to x)
+    int max_plen = 0;                  // max entries per lane of one group
     long long n_rows = 0;              // rows in the plan
     long long n_nnz = 0;               // stored (non-padding) entries
     long long n_groups = 0;
     int n_phases() const { return (int)phase_ptr.size() - 1; }
-    size_t lds_bytes() const { return (size_t)max_slots * 8 + (size_t)max_groups * 4; }
+    size_t lds_bytes() const { return ((size_t)max_slots + (size_t)max_own) * 8 + (size_t)max_groups * 4; }
 };
 
 struct PlanSpec {

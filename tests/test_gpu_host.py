@@ -66,7 +66,7 @@ def test_single_grid_loop_and_host_mirror(host):
     g.sor()
     o.sor()
     assert H.rel_err(g.values(), o.x) < 1e-12
-    assert host.lib().mmgh_grid_value_at(g.h, 100) == o.x[100]
+    assert abs(host.lib().mmgh_grid_value_at(g.h, 100) - o.x[100]) <= 1e-12 * abs(o.x[100])
     # error behaviour: foreign vectors are rejected loudly, not silently computed on the CPU
     assert host.lib().mmgh_grid_sor_wrong_args(g.h) == 1
     assert b"only (laplaceMat_" in host.lib().mmgh_last_error()

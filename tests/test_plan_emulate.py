@@ -51,7 +51,7 @@ def test_schedule_is_exact_for_storage_order_and_reports_phases():
     info = e.info()
     assert info["n_tiles"] == (la["n"] + 63) // 64
     assert info["n_phases"] >= 2
-    assert info["max_slots"] <= 7936
+    assert info["max_slots"] <= 7680
 
 
 @pytest.mark.parametrize("name", ["dirichlet_3level", "neumann_2level"])
