@@ -32,9 +32,12 @@ class _Csc(C.Structure):
 
 def build(fast=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
-    subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+    import sys
+    # make's chatter goes to stderr: bench.py must print exactly one JSON line on stdout
+    subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True, stdout=sys.stderr)
     if fast:
-        subprocess.run(["make", "-s", "-C", _HERE, os.path.join(_HERE, "libmmg_oracle_fast.so")], check=True)
+        subprocess.run(["make", "-s", "-C", _HERE, os.path.join(_HERE, "libmmg_oracle_fast.so")], check=True,
+                       stdout=sys.stderr)
 
 
 _libs = {}

@@ -1,0 +1,69 @@
+"""Condense rocprofv3 output directories (gpurun_out/prof_*) into the small CSV/MD
+summaries committed under profiles/.  Usage:
+    python profiles/summarize.py <tag> <stats_dir> <fetch_dir> <write_dir> [bench.json]
+HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB and
+collected in separate --pmc passes; on gfx950 FETCH_SIZE counts 128-B requests as 64 B
+for wide coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024 (this kernel
+streams 8 B/lane = 512 B per wave-instruction; the factor is the guide's calibration
+for 16 B/lane and is the only correction applied)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def agg_counter(d, counter):
+    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    bench = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else None
+    here = os.path.dirname(os.path.abspath(__file__))
+    ks = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(ks)))
+    with open(os.path.join(here, f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+    fetch = agg_counter(fetch_dir, "FETCH_SIZE")
+    write = agg_counter(write_dir, "WRITE_SIZE")
+    lines = [f"# {tag}: rocprofv3 summary", "",
+             "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+    for r in rows[:8]:
+        lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | "
+                     f"{float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |")
+    lines += ["", "| kernel | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (2*F+W) |", "|---|---|---|---|"]
+    traffic = None
+    for k in fetch:
+        if k not in write:
+            continue
+        fm = sum(fetch[k]) / len(fetch[k])
+        wm = sum(write[k]) / len(write[k])
+        mb = (2 * fm + wm) * 1024 / 1e6
+        if "tile_kernel" in k and (traffic is None or mb > traffic):
+            traffic = mb
+        lines.append(f"| `{k[:70]}` | {fm:.0f} | {wm:.0f} | {mb:.1f} |")
+    if bench:
+        rl = bench["roofline"]
+        cfg = bench["config"]
+        rows_per_launch = cfg["interior_points_per_gpu"] / cfg["phases_per_sweep"]
+        alg = rows_per_launch * rl["algorithmic_bytes_per_row"] / 1e6
+        lines += ["", f"bench line: {bench['value']:.0f} {bench['unit']}, {bench['ms_per_step']:.3f} ms/sweep, "
+                      f"roofline {rl['achieved']:.0f} GB/s = {rl['frac']*100:.1f} % of {rl['peak']:.0f} GB/s; "
+                      f"HIP-event avg launch {rl['avg_launch_us']:.1f} us",
+                  f"algorithmic bytes per sweep-phase launch: {alg:.1f} MB; PMC traffic {traffic:.1f} MB "
+                  f"(ratio {traffic/alg:.2f})" if traffic else ""]
+    open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
