@@ -44,8 +44,8 @@ def parse():
     ap.add_argument("--nside", type=int, default=216, help="points per axis of each rank's cube")
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--polydeg", type=int, default=3)
-    ap.add_argument("--tile", type=int, default=512)
-    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0, help="points per tile (0 = mmg_auto_tile_points)")
+    ap.add_argument("--lanes", type=int, default=2, help="lanes per row of the sweep kernel")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -95,6 +95,12 @@ def main():
     # ---- setup (untimed): cloud -> ordering -> operator -> packed device layout ----
     t_setup = time.perf_counter()
     pts = _host.box_cloud(a.nside, a.dim, seed=12345 + rank)
+    if a.tile <= 0:
+        try:
+            cus, lds = _capi.device_props()
+        except Exception:
+            cus, lds = 0, 0
+        a.tile = _capi.auto_tile_points(len(pts), a.dim, _host.stencil_size(a.polydeg, a.dim), a.lanes, cus, lds)
     grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC,
                                     tile_points=a.tile, lanes_per_row=a.lanes)
     sz = grid.sizes()

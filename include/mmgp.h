@@ -91,6 +91,15 @@ int mmg_set_device(int device);
  * thread's handles; NULL selects the library's own non-blocking stream. */
 int mmg_set_stream(void *hip_stream);
 int mmg_synchronize(void);
+/* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
+int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);
+/* Tile size (points per tile) for Grid::mc_order_points: the largest tile whose
+ * phase (n / tile / 2^dim tiles, one wavefront each) still fits the device in one
+ * residency round -- (2*tile + halo + 1) * 8 B of LDS per wavefront -- so that no
+ * launch ends with a nearly empty second round.  Pure arithmetic, needs no device
+ * when compute_units / lds_bytes_per_cu are passed (> 0). */
+int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per_row, int compute_units,
+                         int lds_bytes_per_cu);
 
 /* ---- level == Grid ------------------------------------------------------- */
 int mmg_level_create(mmg_level **out, const mmg_level_desc *desc);

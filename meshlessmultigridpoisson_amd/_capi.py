@@ -38,6 +38,7 @@ class LevelInfo(C.Structure):
 #: every symbol include/mmgp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
+    "mmg_device_props", "mmg_auto_tile_points",
     "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
     "mmg_level_sor", "mmg_level_sweeps", "mmg_level_bound_eval_neumann", "mmg_level_residual",
@@ -98,6 +99,8 @@ def lib():
         L.mmg_set_stream.argtypes = [vp]
         L.mmg_set_device.argtypes = [C.c_int]
         L.mmg_device_count.argtypes = [_ip]
+        L.mmg_device_props.argtypes = [_ip, _ip]
+        L.mmg_auto_tile_points.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -105,6 +108,17 @@ def lib():
 def check(rc):
     if rc != 0:
         raise MmgError(f"libmmgp error {rc}: {lib().mmg_last_error().decode()}")
+
+
+def auto_tile_points(n_points, dim, stencil, lanes_per_row=0, compute_units=0, lds_bytes_per_cu=0):
+    return lib().mmg_auto_tile_points(int(n_points), int(dim), int(stencil), int(lanes_per_row), int(compute_units),
+                                      int(lds_bytes_per_cu))
+
+
+def device_props():
+    cu, lds = C.c_int(0), C.c_int(0)
+    check(lib().mmg_device_props(C.byref(cu), C.byref(lds)))
+    return cu.value, lds.value
 
 
 def device_count():

@@ -80,6 +80,12 @@ def lib():
     return _lib
 
 
+def stencil_size(polydeg, dim=2):
+    """int(2.5 * polyTerms) -- grid.cpp:266-267 (3-D: (L+1)(L+2)(L+3)/6 terms)."""
+    pt = (polydeg + 1) * (polydeg + 2) * (polydeg + 3) // 6 if dim >= 3 else (polydeg + 1) * (polydeg + 2) // 2
+    return int(2.5 * pt)
+
+
 def _err():
     return lib().mmgh_last_error().decode()
 

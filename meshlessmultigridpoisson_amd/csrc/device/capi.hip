@@ -420,6 +420,54 @@ int mmg_synchronize(void)
     return MMG_OK;
 }
 
+int mmg_device_props(int *compute_units, int *lds_bytes_per_cu)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    HIPC(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIPC(hipGetDeviceProperties(&p, dev));
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    return MMG_OK;
+}
+
+int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per_row, int compute_units,
+                         int lds_bytes_per_cu)
+{
+    if (compute_units <= 0 || lds_bytes_per_cu <= 0) {
+        compute_units = 256;       // MI355X
+        lds_bytes_per_cu = 163840;
+    }
+    const int L = lanes_per_row > 0 ? lanes_per_row : 4;
+    const int wave_cap = L <= 2 ? 8 : 16;  // register-limited wavefronts per CU of the sweep kernel
+    // stencil reach in point spacings, fitted to the staged-halo counts of kNN stencils
+    const double reach = (dim >= 3 ? 1.8 * std::cbrt(stencil / 50.0) : 2.4 * std::sqrt(stencil / 37.0));
+    // 1) smallest tile whose phase fits one residency round (most wavefronts per CU
+    //    without a second, nearly empty round); never below 256 points (short levels
+    //    waste lanes).  2) otherwise the tile with the fullest last round.
+    int best = 0;
+    double best_eff = -1.0;
+    int best_multi = 512;
+    for (int t = 128; t <= 1024; t += 64) {
+        const double side = dim >= 3 ? std::cbrt((double)t) : std::sqrt((double)t);
+        const double halo = std::pow(side + 2 * reach, dim >= 3 ? 3.0 : 2.0) - t;
+        const double lds = (2.0 * t + halo + 1) * 8 + 256;
+        const int per_cu = std::min(wave_cap, (int)(lds_bytes_per_cu / lds));
+        if (per_cu < 1) break;
+        const double rounds = (double)n_points / t / (dim >= 3 ? 8 : 4) / (0.99 * per_cu * compute_units);
+        if (rounds <= 1.0) {
+            if (!best) best = std::max(t, 256);
+        } else {
+            const double eff = rounds / std::ceil(rounds);
+            if (eff >= best_eff) { best_eff = eff; best_multi = t; }
+        }
+    }
+    if (!best) best = best_multi;
+    return best;
+}
+
 int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
 {
     if (!out || !d) return fail(MMG_ERR_INVALID, "null argument");

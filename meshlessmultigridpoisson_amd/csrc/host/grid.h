@@ -54,6 +54,8 @@ public:
     vector<int> tile_ptr_;       // tile boundaries produced by mc_order_points()
     int lanes_per_row_ = 0;      // device layout hints, 0 = automatic
     int tile_size_ = 0;
+    int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy
+    int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
     int setup_threads_ = 0;      // 0 = hardware concurrency
 
     Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source);
@@ -83,7 +85,7 @@ public:
     // inside each tile; storage order = tile colour, tile, point colour.  The
     // sequential SOR of the reference in THIS order is what the GPU executes in
     // parallel (few phases / levels).  Use instead of rcm_order_points().
-    void mc_order_points(int tile_points = 512);
+    void mc_order_points(int tile_points = 0);  // 0: mmg_auto_tile_points()
     void apply_order(const vector<int> &order);  // new index i <- old point order[i] (grid.cpp:744-774)
     // Synthetic throughput operator (not in the reference): kNN-graph Laplacian with
     // inverse-square-distance weights on the reference's stencil pattern

@@ -15,9 +15,13 @@
 // this prediction and the matrix can cost performance, never correctness.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <thread>
 
+#include "../../../include/mmgp.h"
 #include "grid.h"
 
 namespace {
@@ -87,6 +91,7 @@ void par_for(int n, int nth, F f)
 void Grid::mc_order_points(int tile_points)
 {
     const int n = (int)points_.size();
+    if (tile_points <= 0) tile_points = mmg_auto_tile_points(n, dim_, properties_.stencilSize, lanes_per_row_, 0, 0);
     if (tile_points < 8) tile_points = 8;
     ensure_knn();
     const int nth = threads();
@@ -110,12 +115,71 @@ void Grid::mc_order_points(int tile_points)
     }
 
     // ---- 1. spatial tiles ---------------------------------------------------------
+    // Default: equal-count slabs along x, each cut into equal-count bars along y,
+    // each cut into equal-count boxes along z (a logically Cartesian tile grid).
+    // Tiles that couple then differ by exactly one step in at least one grid
+    // index, so the parity colouring (ix%2, iy%2, iz%2) -- 4 colours in 2-D, 8 in
+    // 3-D, all equally populated -- is proper whenever a tile is at least one
+    // stencil reach wide.  tiling_ == 1 selects kd-tree leaves + greedy colouring.
     vector<int> idx((size_t)n);
     std::iota(idx.begin(), idx.end(), 0);
     vector<int> bounds;
-    KdSplit kd{points_, dim_, tile_points, idx, {}};
-    kd.run(0, n, bounds, 0);
-    std::sort(bounds.begin(), bounds.end());
+    vector<int> parity_colour;  // per tile, slab tiling only
+    if (tiling_ == 1) {
+        KdSplit kd{points_, dim_, tile_points, idx, {}};
+        kd.run(0, n, bounds, 0);
+        std::sort(bounds.begin(), bounds.end());
+    } else {
+        double ext[3] = {1, 1, 1};
+        for (int a2 = 0; a2 < dim_; ++a2) {
+            double mn = 1e300, mx = -1e300;
+            for (const Point &p : points_) { mn = std::min(mn, comp(p, a2)); mx = std::max(mx, comp(p, a2)); }
+            ext[a2] = std::max(mx - mn, 1e-300);
+        }
+        const double n_leaf = std::max(1.0, (double)n / tile_points);
+        int m[3] = {1, 1, 1};
+        double vol = 1.0;
+        for (int a2 = 0; a2 < dim_; ++a2) vol *= ext[a2];
+        for (int a2 = 0; a2 < dim_; ++a2)
+            m[a2] = std::max(1, (int)std::floor(std::pow(n_leaf / vol, 1.0 / dim_) * ext[a2] + 0.5));
+        while ((double)m[0] * m[1] * m[2] * tile_points < (double)n) {  // keep tiles <= tile_points
+            int best = 0;
+            for (int a2 = 1; a2 < dim_; ++a2)
+                if (ext[a2] / m[a2] > ext[best] / m[best]) best = a2;
+            m[best]++;
+        }
+        auto by_axis = [&](int ax) {
+            return [this, ax](int x, int y) {
+                const double vx = comp(points_[(size_t)x], ax), vy = comp(points_[(size_t)y], ax);
+                return vx < vy || (vx == vy && x < y);
+            };
+        };
+        auto cut = [](int lo, int hi, int parts, int k) { return lo + (int)((long long)(hi - lo) * k / parts); };
+        std::sort(idx.begin(), idx.end(), by_axis(0));
+        vector<std::pair<int, int>> slabs;
+        for (int ix = 0; ix < m[0]; ++ix) slabs.emplace_back(cut(0, n, m[0], ix), cut(0, n, m[0], ix + 1));
+        vector<vector<int>> sb((size_t)m[0]), sc((size_t)m[0]);
+        par_for(m[0], nth, [&](int ix) {
+            const int lo = slabs[(size_t)ix].first, hi = slabs[(size_t)ix].second;
+            if (dim_ >= 2) std::sort(idx.begin() + lo, idx.begin() + hi, by_axis(1));
+            for (int iy = 0; iy < m[1]; ++iy) {
+                const int l2 = cut(lo, hi, m[1], iy), h2 = cut(lo, hi, m[1], iy + 1);
+                if (dim_ >= 3) std::sort(idx.begin() + l2, idx.begin() + h2, by_axis(2));
+                for (int iz = 0; iz < m[2]; ++iz) {
+                    const int l3 = cut(l2, h2, m[2], iz), h3 = cut(l2, h2, m[2], iz + 1);
+                    if (h3 > l3) {
+                        sb[(size_t)ix].push_back(l3);
+                        sc[(size_t)ix].push_back((ix & 1) | ((iy & 1) << 1) | ((iz & 1) << 2));
+                    }
+                }
+            }
+        });
+        for (int ix = 0; ix < m[0]; ++ix) {
+            bounds.insert(bounds.end(), sb[(size_t)ix].begin(), sb[(size_t)ix].end());
+            parity_colour.insert(parity_colour.end(), sc[(size_t)ix].begin(), sc[(size_t)ix].end());
+        }
+        if (std::getenv("MMG_VERBOSE")) std::fprintf(stderr, "[mc_order_points] slab tiling %d x %d x %d\n", m[0], m[1], m[2]);
+    }
     bounds.push_back(n);
     const int nt = (int)bounds.size() - 1;
     vector<int> tile_of((size_t)n), pos_in((size_t)n);
@@ -146,19 +210,45 @@ void Grid::mc_order_points(int tile_points)
         for (int t = 0; t < nt; ++t)
             for (int u : fwd[(size_t)t]) { tnb[(size_t)t].push_back(u); tnb[(size_t)u].push_back(t); }
     }
+    // Balanced greedy: among the colours no coupled tile uses, take the least
+    // populated one; open a new colour only when none is free.  Phases of similar
+    // size keep every launch in the bandwidth-bound regime (a phase costs at least
+    // one tile's latency chain however few tiles it holds).
     vector<int> tcol((size_t)nt, -1);
-    {
-        vector<int> mark;
+    int ncol = std::max(1, tile_colours_ > 0 ? tile_colours_ : (dim_ >= 3 ? 10 : 5));
+    if (!parity_colour.empty()) {
+        tcol = parity_colour;  // any residual conflict is resolved by libmmgp's own levelisation
+        for (auto &v : tnb) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+        if (std::getenv("MMG_VERBOSE")) {
+            long long bad = 0;
+            for (int t = 0; t < nt; ++t)
+                for (int u : tnb[(size_t)t]) bad += (u < t && tcol[(size_t)u] == tcol[(size_t)t]);
+            std::fprintf(stderr, "[mc_order_points] %d tiles, parity colouring, %lld same-colour couplings\n", nt, bad);
+        }
+    } else {
+        vector<long long> load((size_t)ncol, 0);
+        vector<char> used;
         for (int t = 0; t < nt; ++t) {
             auto &v = tnb[(size_t)t];
             std::sort(v.begin(), v.end());
             v.erase(std::unique(v.begin(), v.end()), v.end());
-            mark.assign(v.size() + 2, 0);
+            used.assign((size_t)ncol, 0);
             for (int u : v)
-                if (tcol[(size_t)u] >= 0 && tcol[(size_t)u] < (int)mark.size()) mark[(size_t)tcol[(size_t)u]] = 1;
-            int c = 0;
-            while (mark[(size_t)c]) ++c;
-            tcol[(size_t)t] = c;
+                if (tcol[(size_t)u] >= 0) used[(size_t)tcol[(size_t)u]] = 1;
+            int best = -1;
+            for (int c = 0; c < ncol; ++c)
+                if (!used[(size_t)c] && (best < 0 || load[(size_t)c] < load[(size_t)best])) best = c;
+            if (best < 0) {
+                best = ncol++;
+                load.push_back(0);
+            }
+            tcol[(size_t)t] = best;
+            load[(size_t)best] += bounds[(size_t)t + 1] - bounds[(size_t)t];
+        }
+        if (std::getenv("MMG_VERBOSE")) {
+            std::fprintf(stderr, "[mc_order_points] %d tiles, %d colours:", nt, ncol);
+            for (long long l : load) std::fprintf(stderr, " %lld", l);
+            std::fprintf(stderr, "\n");
         }
     }
 
