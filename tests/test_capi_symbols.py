@@ -1,0 +1,69 @@
+"""The C-ABI shared library loads on a GPU-less host, exports every symbol
+include/mmgp.h declares, carries a gfx950 code object, and refuses to compute
+without a device (no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+ROOT = H.ROOT
+
+
+def _lib_path():
+    from meshlessmultigridpoisson_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        pytest.skip("libmmgp.so not built (run __graft_entry__.build())")
+    return _capi.LIB_PATH
+
+
+def test_header_symbols_are_exported():
+    from meshlessmultigridpoisson_amd import _capi
+    L = C.CDLL(_lib_path())
+    header = open(os.path.join(ROOT, "include", "mmgp.h")).read()
+    declared = sorted(set(re.findall(r"\b(mmg_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in mmgp.h but not exported"
+    assert sorted(_capi.SYMBOLS) == declared, "python binding list out of sync with mmgp.h"
+
+
+def test_library_contains_gfx950_code_object():
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = shutil.copy(_lib_path(), d)
+        out = subprocess.run([objdump, "--offloading", p], capture_output=True, text=True, cwd=d).stdout
+    assert "gfx950" in out and "gfx906" not in out, out
+
+
+def test_no_cpu_fallback_without_device():
+    from meshlessmultigridpoisson_amd import _capi
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    case = H.load_case("dirichlet_3level")
+    with pytest.raises(_capi.MmgError, match="no HIP device"):
+        H.device_level(H.level_arrays(case, 0))
+    h = C.c_void_p()
+    rc = _capi.lib().mmg_transfer_create(C.byref(h), 1, 1, None, None, None, 0)
+    assert rc != 0
+
+
+def test_host_library_loads_and_links_capi():
+    from meshlessmultigridpoisson_amd import _host
+    L = _host.lib()
+    for name in ("mmgh_mg_create_square", "mmgh_grid_sor", "mmgh_points_from_msh", "mmgh_mg_vcycle"):
+        assert hasattr(L, name)
+
+
+def test_auto_tile_points_is_device_free_arithmetic():
+    from meshlessmultigridpoisson_amd import _capi
+    assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 640  # one residency round per phase
+    assert _capi.auto_tile_points(10000, 2, 37, 4, 256, 163840) == 256
