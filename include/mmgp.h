@@ -141,6 +141,25 @@ int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out);
  * per-launch average must agree with rocprofv3 --kernel-trace --stats. */
 int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches);
 
+/* ---- multi-GPU: domain decomposition with RCCL ghost exchange ----------------
+ * One process per GPU.  A rank's level holds its OWNED points first and then the
+ * GHOST points (copies of points owned by other ranks that its rows reference),
+ * grouped by owner.  Ghost points carry bcflags == 3: never relaxed, no residual
+ * row, refreshed only by the exchange.  Schedule ("block-hybrid Gauss-Seidel"):
+ * ghosts are refreshed once before every sweep and before every residual, i.e. a
+ * row sees the current sweep's values of its own rank and the previous sweep's
+ * values of the others -- the schedule oracle/mmg_oracle.c:orc_sor_hybrid states.
+ * Norms are all-reduced (2 doubles).  Neumann levels are not distributed yet. */
+int mmg_comm_get_unique_id(char *id128);   /* 128 bytes; the caller broadcasts rank 0's */
+int mmg_comm_init(int rank, int nranks, const char *id128);
+int mmg_comm_finalize(void);
+/* nbr_rank[n_nbr]; send_idx[send_ptr[k]..send_ptr[k+1]) = local indices of owned
+ * points whose values neighbour k needs; ghosts received from neighbour k land at
+ * x[n_owned_points + recv_ptr[k] .. n_owned_points + recv_ptr[k+1]). */
+int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const int *nbr_rank,
+                           const int *send_ptr, const int *send_idx, const int *recv_ptr);
+int mmg_level_exchange(mmg_level *lv);
+
 /* ---- transfers == restrictionMatrices_/prolongMatrices_ ------------------- */
 /* The reference stores them column-major (multigrid.h:8-9): pass
  * outer=colptr[cols+1], inner=row indices with col_major=1; a row-major CSR

@@ -38,7 +38,8 @@ class LevelInfo(C.Structure):
 #: every symbol include/mmgp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
-    "mmg_device_props", "mmg_auto_tile_points",
+    "mmg_device_props", "mmg_auto_tile_points", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
+    "mmg_level_set_exchange", "mmg_level_exchange",
     "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
     "mmg_level_sor", "mmg_level_sweeps", "mmg_level_bound_eval_neumann", "mmg_level_residual",
@@ -100,6 +101,10 @@ def lib():
         L.mmg_set_device.argtypes = [C.c_int]
         L.mmg_device_count.argtypes = [_ip]
         L.mmg_device_props.argtypes = [_ip, _ip]
+        L.mmg_comm_get_unique_id.argtypes = [C.c_char_p]
+        L.mmg_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
+        L.mmg_level_set_exchange.argtypes = [vp, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
+        L.mmg_level_exchange.argtypes = [vp]
         L.mmg_auto_tile_points.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
@@ -113,6 +118,20 @@ def check(rc):
 def auto_tile_points(n_points, dim, stencil, lanes_per_row=0, compute_units=0, lds_bytes_per_cu=0):
     return lib().mmg_auto_tile_points(int(n_points), int(dim), int(stencil), int(lanes_per_row), int(compute_units),
                                       int(lds_bytes_per_cu))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().mmg_comm_get_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(rank, nranks, id128):
+    check(lib().mmg_comm_init(int(rank), int(nranks), id128))
+
+
+def comm_finalize():
+    check(lib().mmg_comm_finalize())
 
 
 def device_props():
@@ -195,6 +214,13 @@ class Level:
         if getattr(self, "h", None) and _lib is not None and not getattr(self, "_borrowed", False):
             _lib.mmg_level_destroy(self.h)
             self.h = None
+
+    def set_exchange(self, n_owned, nbr_rank, send_ptr, send_idx, recv_ptr):
+        nbr, sp, si, rp = _i(nbr_rank), _i(send_ptr), _i(send_idx), _i(recv_ptr)
+        check(lib().mmg_level_set_exchange(self.h, int(n_owned), len(nbr), _pi(nbr), _pi(sp), _pi(si), _pi(rp)))
+
+    def exchange(self):
+        check(lib().mmg_level_exchange(self.h))
 
     def time_phases(self, nsweeps):
         ms, cnt = C.c_float(0), C.c_int(0)

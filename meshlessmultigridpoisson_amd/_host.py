@@ -76,6 +76,14 @@ def lib():
         L.mmgh_order_from_txt.argtypes = [C.c_char_p, C.c_int]
         L.mmgh_write_msh.argtypes = [C.c_char_p, _dp, C.c_int]
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
+        L.mmgh_grid_partition_slabs.argtypes = [vp, C.c_int, _ip]
+        L.mmgh_grid_extract_subdomain.restype = vp
+        L.mmgh_grid_extract_subdomain.argtypes = [vp, _ip, C.c_int]
+        L.mmgh_grid_n_owned.argtypes = [vp]
+        L.mmgh_grid_local_map.argtypes = [vp, _ip, _ip]
+        L.mmgh_grid_create_local.restype = vp
+        L.mmgh_grid_create_local.argtypes = [C.c_int, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_double, C.c_int]
         _lib = L
     return _lib
 
@@ -126,6 +134,42 @@ class Grid:
         if getattr(self, "_own", False) and self.h and _lib is not None:
             _lib.mmgh_grid_destroy(self.h)
             self.h = None
+
+    # ---- domain decomposition ---------------------------------------------------------
+    def partition_slabs(self, nparts):
+        part = np.zeros(self.sizes()["n"], dtype=np.int32)
+        lib().mmgh_grid_partition_slabs(self.h, int(nparts), part.ctypes.data_as(_ip))
+        return part
+
+    def extract_subdomain(self, part, rank):
+        part = _i(part)
+        h = lib().mmgh_grid_extract_subdomain(self.h, part.ctypes.data_as(_ip), int(rank))
+        if not h:
+            raise HostError(_err())
+        g = Grid(h)
+        g._own = True
+        return g
+
+    @classmethod
+    def create_local(cls, points, flags, gid, owner, dim, stencil, tile_points=0, lanes_per_row=0, omega=1.4, iters=5):
+        pts, flags, gid, owner = _d(points).reshape(-1, 3), _i(flags), _i(gid), _i(owner)
+        h = lib().mmgh_grid_create_local(len(pts), pts.ctypes.data_as(_dp), flags.ctypes.data_as(_ip),
+                                         gid.ctypes.data_as(_ip), owner.ctypes.data_as(_ip), dim, stencil, tile_points,
+                                         lanes_per_row, omega, iters)
+        if not h:
+            raise HostError(_err())
+        g = cls(h)
+        g._own = True
+        return g
+
+    def local_map(self):
+        """(n_owned, gid[n_local], ghost_owner[n_ghost]) of a sub-domain grid."""
+        n = self.sizes()["n"]
+        no = lib().mmgh_grid_n_owned(self.h)
+        gid = np.zeros(n, dtype=np.int32)
+        own = np.zeros(max(n - no, 1), dtype=np.int32)
+        lib().mmgh_grid_local_map(self.h, gid.ctypes.data_as(_ip), own.ctypes.data_as(_ip))
+        return no, gid, own[: n - no]
 
     def sizes(self):
         out = np.zeros(8, dtype=np.int32)
@@ -338,3 +382,68 @@ def box_cloud(nside, dim, seed=12345, jitter=0.25):
     jit = (rng.random((len(pts), dim)) * 2 - 1) * jitter * h
     pts[interior, :dim] += jit[interior]
     return pts
+
+
+# ---- domain decomposition helpers (setup-time, host side) --------------------------------
+def build_exchange_lists(rank, n_owned, gid, ghost_owner, all_gather_object):
+    """Who sends what to whom.  Ghosts are grouped by owner (ascending), so the values
+    received from one neighbour form one contiguous segment of the ghost range.
+    all_gather_object(obj) -> list of every rank's obj (torch.distributed / a test stub).
+    Returns (nbr_rank, send_ptr, send_idx, recv_ptr) for mmg_level_set_exchange."""
+    ghost_gid = gid[n_owned:]
+    need = {}
+    for o in np.unique(ghost_owner):
+        need[int(o)] = ghost_gid[ghost_owner == o]
+    everyone = all_gather_object(need)           # everyone[q][r] = gids q needs from r
+    order = np.argsort(gid[:n_owned], kind="stable")
+    sorted_gid = gid[:n_owned][order]
+    nbrs = sorted(set(need.keys()) | {q for q, d in enumerate(everyone) if rank in d and q != rank})
+    send_ptr, send_idx, recv_ptr = [0], [], [0]
+    for q in nbrs:
+        wanted = everyone[q].get(rank, np.zeros(0, dtype=np.int32)) if q != rank else np.zeros(0, dtype=np.int32)
+        pos = np.searchsorted(sorted_gid, wanted)
+        assert np.all(sorted_gid[pos] == wanted), "a neighbour asks for a point this rank does not own"
+        send_idx.extend(order[pos].tolist())
+        send_ptr.append(len(send_idx))
+        recv_ptr.append(recv_ptr[-1] + len(need.get(q, [])))
+    return (np.array(nbrs, dtype=np.int32), np.array(send_ptr, dtype=np.int32), np.array(send_idx, dtype=np.int32),
+            np.array(recv_ptr, dtype=np.int32))
+
+
+def _jitter_hash(gid, axis, seed):
+    """Counter-based uniform(-1,1): every rank computes the same jitter for a lattice point."""
+    z = (gid.astype(np.uint64) * np.uint64(3) + np.uint64(axis)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed)
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return (z >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
+
+
+def slab_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25):
+    """Rank's part of a (nranks*nside) x nside [x nside] jittered lattice on [0,nranks]x[0,1]^(dim-1):
+    its own nside x-layers plus `margin` layers of each neighbour as ghost candidates.
+    Returns (points, flags, gid, owner); flags 0 interior / 1 global Dirichlet boundary / 3 margin."""
+    h = 1.0 / (nside - 1)
+    nx_glob = nranks * nside
+    lo = max(0, rank * nside - margin)
+    hi = min(nx_glob, (rank + 1) * nside + margin)
+    ix = np.arange(lo, hi)
+    if dim == 3:
+        IZ, IY, IX = np.meshgrid(np.arange(nside), np.arange(nside), ix, indexing="ij")
+        idx = np.stack([IX.ravel(), IY.ravel(), IZ.ravel()], axis=1)
+        gid = (idx[:, 2] * nside + idx[:, 1]) * nx_glob + idx[:, 0]
+    else:
+        IY, IX = np.meshgrid(np.arange(nside), ix, indexing="ij")
+        idx = np.stack([IX.ravel(), IY.ravel(), np.zeros(IX.size, dtype=np.int64)], axis=1)
+        gid = idx[:, 1] * nx_glob + idx[:, 0]
+    pts = idx.astype(np.float64) * h
+    bnd = (idx[:, 0] == 0) | (idx[:, 0] == nx_glob - 1) | (idx[:, 1] == 0) | (idx[:, 1] == nside - 1)
+    if dim == 3:
+        bnd |= (idx[:, 2] == 0) | (idx[:, 2] == nside - 1)
+    for a in range(dim):
+        pts[~bnd, a] += _jitter_hash(gid[~bnd], a, seed) * jitter * h
+    owner = (idx[:, 0] // nside).astype(np.int32)
+    flags = np.where(owner == rank, bnd.astype(np.int32), 3).astype(np.int32)
+    return pts, flags, gid.astype(np.int32), owner

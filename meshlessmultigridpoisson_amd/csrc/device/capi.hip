@@ -1,6 +1,7 @@
 // capi.cpp -- implementation of include/mmgp.h on top of the packed plans and
 // the gfx950 kernels.  Host logic only (built by hipcc for the HIP runtime API).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -50,6 +51,56 @@ int ensure_device()
     }
     return MMG_OK;
 }
+
+// ---- RCCL, loaded lazily so that single-GPU users never touch it -----------------
+typedef struct ncclComm *ncclComm_t;
+struct NcclId { char internal[128]; };
+struct Rccl {
+    void *so = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+};
+Rccl g_rccl;
+constexpr int kNcclDouble = 8;  // ncclFloat64
+constexpr int kNcclSum = 0;
+
+int rccl_load()
+{
+    if (g_rccl.so) return MMG_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names)
+        if ((g_rccl.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!g_rccl.so) return fail(MMG_ERR_COMM, std::string("cannot load librccl: ") + dlerror());
+#define RSYM(field, name)                                                                    \
+    *(void **)(&g_rccl.field) = dlsym(g_rccl.so, name);                                      \
+    if (!g_rccl.field) return fail(MMG_ERR_COMM, std::string("librccl lacks ") + name);
+    RSYM(GetUniqueId, "ncclGetUniqueId")
+    RSYM(CommInitRank, "ncclCommInitRank")
+    RSYM(CommDestroy, "ncclCommDestroy")
+    RSYM(GroupStart, "ncclGroupStart")
+    RSYM(GroupEnd, "ncclGroupEnd")
+    RSYM(Send, "ncclSend")
+    RSYM(Recv, "ncclRecv")
+    RSYM(AllReduce, "ncclAllReduce")
+    RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+    return MMG_OK;
+}
+
+#define NCCLC(call)                                                                                  \
+    do {                                                                                             \
+        int r_ = (call);                                                                             \
+        if (r_ != 0) return fail(MMG_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
 
 template <class T>
 struct DevBuf {
@@ -144,6 +195,12 @@ struct mmg_level {
     DevBuf<double> dir_vals, neu_vals;
     DevBuf<double> partA, partX, partB, partBn, scal;
     int n_absb = 0;
+    // domain decomposition (mmg_level_set_exchange)
+    bool distributed = false;
+    int n_owned = 0;
+    std::vector<int> nbr, send_ptr, recv_ptr;
+    DevBuf<int32_t> send_idx;
+    DevBuf<double> sendbuf;
 };
 
 struct mmg_transfer {
@@ -175,6 +232,23 @@ int build_gather_plan(const CsrView &A, const std::vector<int32_t> &rows, int L,
     const std::string err = build_gather_plan_host(A, rows, L, tile_rows, diag, self, in_place, mult_col, &P);
     if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "plan: " + err);
     return out->upload(P);
+}
+
+// refresh the ghost copies: pack owned boundary-layer values, one grouped send/recv
+// per neighbour straight into the ghost segment of x (ghosts are grouped by owner)
+int exchange(mmg_level *lv)
+{
+    if (!lv->distributed || lv->nbr.empty()) return MMG_OK;
+    if (!g_rccl.comm) return fail(MMG_ERR_COMM, "mmg_comm_init has not been called");
+    HIPC(launch_gather(lv->sendbuf.p, lv->x.p, lv->send_idx.p, (int)lv->send_idx.n, g_stream));
+    NCCLC(g_rccl.GroupStart());
+    for (size_t k = 0; k < lv->nbr.size(); ++k) {
+        const int ns = lv->send_ptr[k + 1] - lv->send_ptr[k], nr = lv->recv_ptr[k + 1] - lv->recv_ptr[k];
+        if (ns > 0) NCCLC(g_rccl.Send(lv->sendbuf.p + lv->send_ptr[k], (size_t)ns, kNcclDouble, lv->nbr[k], g_rccl.comm, g_stream));
+        if (nr > 0) NCCLC(g_rccl.Recv(lv->x.p + lv->n_owned + lv->recv_ptr[k], (size_t)nr, kNcclDouble, lv->nbr[k], g_rccl.comm, g_stream));
+    }
+    NCCLC(g_rccl.GroupEnd());
+    return MMG_OK;
 }
 
 int sweep_once(mmg_level *lv)
@@ -217,7 +291,9 @@ int bound_eval(mmg_level *lv)
 int sweeps(mmg_level *lv, int k)
 {
     for (int it = 0; it < k; ++it) {
-        int rc = sweep_once(lv);
+        int rc = exchange(lv);
+        if (rc) return rc;
+        rc = sweep_once(lv);
         if (rc) return rc;
         rc = bound_eval(lv);
         if (rc) return rc;
@@ -228,6 +304,10 @@ int sweeps(mmg_level *lv, int k)
 // r = b - A x with Dirichlet rows zeroed; scal[0] = ||r||_1, scal[1] = ||b||_1
 int residual_dev(mmg_level *lv, bool norms)
 {
+    {
+        const int rc = exchange(lv);
+        if (rc) return rc;
+    }
     TileArgs a{};
     a.p = lv->A.dev;
     a.tile_list = nullptr;
@@ -255,6 +335,8 @@ int residual_dev(mmg_level *lv, bool norms)
     HIPC(launch_resid_finalize(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
                                lv->partBn.p, norms ? lv->n_absb : 0, lv->partX.p, lv->A.n_tiles, lv->x.p, lv->b.p,
                                lv->r.p, lv->n, lv->neumann, lv->scal.p, g_stream));
+    if (lv->distributed && g_rccl.comm && g_rccl.nranks > 1)
+        NCCLC(g_rccl.AllReduce(lv->scal.p, lv->scal.p, 2, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
     return MMG_OK;
 }
 
@@ -736,6 +818,68 @@ int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+int mmg_comm_get_unique_id(char *id128)
+{
+    if (!id128) return fail(MMG_ERR_INVALID, "null id");
+    int rc = rccl_load();
+    if (rc) return rc;
+    NcclId id;
+    NCCLC(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, id.internal, 128);
+    return MMG_OK;
+}
+
+int mmg_comm_init(int rank, int nranks, const char *id128)
+{
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(MMG_ERR_INVALID, "comm_init: bad argument");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = rccl_load())) return rc;
+    if (g_rccl.comm) return fail(MMG_ERR_INVALID, "comm already initialised");
+    NcclId id;
+    std::memcpy(id.internal, id128, 128);
+    NCCLC(g_rccl.CommInitRank(&g_rccl.comm, nranks, id, rank));
+    g_rccl.rank = rank;
+    g_rccl.nranks = nranks;
+    return MMG_OK;
+}
+
+int mmg_comm_finalize(void)
+{
+    if (g_rccl.comm) {
+        (void)hipStreamSynchronize(g_stream);
+        NCCLC(g_rccl.CommDestroy(g_rccl.comm));
+        g_rccl.comm = nullptr;
+    }
+    return MMG_OK;
+}
+
+int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const int *nbr_rank, const int *send_ptr,
+                           const int *send_idx, const int *recv_ptr)
+{
+    if (!lv || n_owned_points < 0 || n_owned_points > lv->n || n_nbr < 0) return fail(MMG_ERR_INVALID, "set_exchange: bad argument");
+    if (lv->neumann) return fail(MMG_ERR_UNSUPPORTED, "distributed Neumann levels (all-reduced multiplier row) are not implemented");
+    if (n_nbr > 0 && (!nbr_rank || !send_ptr || !recv_ptr)) return fail(MMG_ERR_INVALID, "set_exchange: null lists");
+    lv->nbr.assign(nbr_rank, nbr_rank + n_nbr);
+    lv->send_ptr.assign(send_ptr, send_ptr + (n_nbr ? n_nbr + 1 : 0));
+    lv->recv_ptr.assign(recv_ptr, recv_ptr + (n_nbr ? n_nbr + 1 : 0));
+    const int ns = n_nbr ? send_ptr[n_nbr] : 0, nr = n_nbr ? recv_ptr[n_nbr] : 0;
+    if (n_owned_points + nr > lv->n) return fail(MMG_ERR_INVALID, "set_exchange: ghost segment exceeds the level");
+    for (int k = 0; k < ns; ++k)
+        if (send_idx[k] < 0 || send_idx[k] >= n_owned_points) return fail(MMG_ERR_INVALID, "set_exchange: send index is not an owned point");
+    HIPC(lv->send_idx.upload(send_idx, (size_t)ns));
+    HIPC(lv->sendbuf.alloc((size_t)std::max(ns, 1)));
+    lv->n_owned = n_owned_points;
+    lv->distributed = true;
+    return MMG_OK;
+}
+
+int mmg_level_exchange(mmg_level *lv)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    return exchange(lv);
 }
 
 int mmg_transfer_create(mmg_transfer **out, int rows, int cols, const int *outer, const int *inner,

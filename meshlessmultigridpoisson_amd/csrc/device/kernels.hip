@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
         for (uint32_t i = lane; i < n_own; i += 64) {
             const double v = xs[i];
             a.out[td.row0 + i] = v;
-            if (a.partial && a.flags8[td.row0 + i] != 2) s += v;
+            if (a.partial && a.flags8[td.row0 + i] < 2) s += v;
         }
         if (a.partial) {
             s = wave_sum(s);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
         if (a.partial2) {
             double s = 0.0;
             for (uint32_t i = lane; i < n_own; i += 64)
-                if (a.flags8[td.row0 + i] != 2) s += xs[i];
+                if (a.flags8[td.row0 + i] < 2) s += xs[i];
             s = wave_sum(s);
             if (lane == 0) a.partial2[tile] = s;
         }
@@ -279,6 +279,11 @@ hipError_t launch_L(TileMode mode, const TileArgs &a, hipStream_t s)
 __global__ void k_fill(double *v, long long n, double c)
 {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) v[i] = c;
+}
+__global__ void k_gather(double *dst, const double *src, const int32_t *idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
 }
 __global__ void k_scatter_const(double *v, const int32_t *idx, int n, double c)
 {
@@ -385,6 +390,12 @@ hipError_t launch_fill(double *v, long long n, double c, hipStream_t s)
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, s, v, n, c);
+    return hipGetLastError();
+}
+hipError_t launch_gather(double *dst, const double *src, const int32_t *idx, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, idx, n);
     return hipGetLastError();
 }
 hipError_t launch_scatter_const(double *v, const int32_t *idx, int n, double c, hipStream_t s)

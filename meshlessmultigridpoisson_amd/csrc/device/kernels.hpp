@@ -43,6 +43,7 @@ struct TileArgs {
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
 
 hipError_t launch_fill(double *v, long long n, double c, hipStream_t s);
+hipError_t launch_gather(double *dst, const double *src, const int32_t *idx, int n, hipStream_t s);
 hipError_t launch_scatter_const(double *v, const int32_t *idx, int n, double c, hipStream_t s);
 hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);
 // x[n] <- (1-w) x[n] + w (b[n] - sum(partial))            (grid.cpp:118-141, row N)

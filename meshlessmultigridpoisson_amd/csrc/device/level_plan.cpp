@@ -50,7 +50,9 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
     std::vector<int32_t> pt_tile;
     if (d.tile_ptr && d.n_tiles > 0) {
         pt_tile.assign(d.tile_ptr, d.tile_ptr + d.n_tiles + 1);
-        if (pt_tile.front() != 0 || pt_tile.back() != n) return "tile_ptr must cover [0,n)";
+        // tiles may stop short of n: the tail (ghost points of a distributed level) is
+        // nobody's own range and is reached through the halo lists only
+        if (pt_tile.front() != 0 || pt_tile.back() > n) return "tile_ptr must start at 0 and end at or before n";
         for (size_t i = 1; i < pt_tile.size(); ++i)
             if (pt_tile[i] < pt_tile[i - 1]) return "tile_ptr must be non-decreasing";
     } else {
@@ -62,6 +64,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
     rows.reserve(n);
     for (int i = 0; i < n; ++i)
         if (d.bcflags[i] == 0) rows.push_back(i);
+    if (!rows.empty() && rows.back() >= pt_tile.back()) return "an interior row lies outside every tile";
     std::string err;
     L = widen_L(A, rows.data(), (int64_t)rows.size(), L);
     for (int attempt = 0; attempt < 10; ++attempt) {
@@ -96,7 +99,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
             const int mid = (pt_tile[t] + pt_tile[t + 1]) / 2;
             if (mid > pt_tile[t] && mid < pt_tile[t + 1]) split.push_back(mid);
         }
-        split.push_back(n);
+        split.push_back(pt_tile.back());
         pt_tile.swap(split);
     }
     return err;

@@ -330,6 +330,7 @@ void Grid::build_laplacian()
     std::vector<std::vector<double>> W((size_t)n);
     std::vector<vector<int>> NB((size_t)n);
     parallel_for(n, threads(), [&](int i) {
+        if (bcFlags_[(size_t)i] == kGhost) return;  // ghost points own no row
         auto w = laplaceWeights(i);
         W[(size_t)i] = w.first.host();
         NB[(size_t)i] = std::move(w.second);
@@ -337,7 +338,7 @@ void Grid::build_laplacian()
     vector<Triplet> trip, btrip;
     trip.reserve((size_t)n * (size_t)(properties_.stencilSize + 2));
     for (int i = 0; i < n; ++i) {
-        if (bcFlags_[(size_t)i] != 2) {
+        if (bcFlags_[(size_t)i] != 2 && bcFlags_[(size_t)i] != kGhost) {
             for (size_t j = 0; j < NB[(size_t)i].size(); ++j) {
                 const int c = NB[(size_t)i][j];
                 const double v = W[(size_t)i][j];
@@ -394,11 +395,13 @@ void Grid::build_graph_laplacian()
     const int n = laplaceMatSize_;
     const int K = properties_.stencilSize;
     ensure_knn();
-    std::vector<int> outer((size_t)n + 1, 0), inner((size_t)n * (size_t)K);
-    std::vector<double> val((size_t)n * (size_t)K);
-    for (int i = 0; i <= n; ++i) outer[(size_t)i] = i * K;
-    double h2 = 1.0 / std::pow((double)n, 2.0 / dim_);
+    std::vector<int> outer((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) outer[(size_t)i + 1] = outer[(size_t)i] + (bcFlags_[(size_t)i] == kGhost ? 0 : K);
+    std::vector<int> inner((size_t)outer[(size_t)n]);
+    std::vector<double> val((size_t)outer[(size_t)n]);
+    const double h2 = 1.0 / std::pow((double)n, 2.0 / dim_);
     parallel_for(n, threads(), [&](int i) {
+        if (bcFlags_[(size_t)i] == kGhost) return;
         std::vector<std::pair<double, int>> res;
         knn_.knn(points_[(size_t)i], K, std::function<bool(int)>(), res);
         std::vector<std::pair<int, double>> row;
@@ -412,14 +415,120 @@ void Grid::build_graph_laplacian()
         }
         row.emplace_back(i, -sum);
         std::sort(row.begin(), row.end());
+        const size_t base = (size_t)outer[(size_t)i];
         for (size_t k = 0; k < row.size(); ++k) {
-            inner[(size_t)i * K + k] = row[k].first;
-            val[(size_t)i * K + k] = row[k].second;
+            inner[base + k] = row[k].first;
+            val[base + k] = row[k].second;
         }
     });
     delete laplaceMat_;
     laplaceMat_ = new SparseRowMajor(n, n, true);
     laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(val));
+}
+
+vector<int> Grid::partition_slabs(int nparts)
+{
+    const int n = (int)points_.size();
+    vector<int> part((size_t)n, 0);
+    if (nparts <= 1) return part;
+    auto xof = [&](int i) { return std::get<0>(points_[(size_t)i]); };
+    if (!tile_ptr_.empty()) {
+        const int nt = (int)tile_ptr_.size() - 1;
+        vector<std::pair<double, int>> cx((size_t)nt);
+        for (int t = 0; t < nt; ++t) {
+            double s = 0;
+            for (int i = tile_ptr_[(size_t)t]; i < tile_ptr_[(size_t)t + 1]; ++i) s += xof(i);
+            cx[(size_t)t] = std::make_pair(s / std::max(1, tile_ptr_[(size_t)t + 1] - tile_ptr_[(size_t)t]), t);
+        }
+        std::sort(cx.begin(), cx.end());
+        long long acc = 0;
+        for (auto &c : cx) {
+            const int t = c.second;
+            const int p = (int)std::min<long long>(nparts - 1, acc * nparts / std::max(1, tile_ptr_.back()));
+            for (int i = tile_ptr_[(size_t)t]; i < tile_ptr_[(size_t)t + 1]; ++i) part[(size_t)i] = p;
+            acc += tile_ptr_[(size_t)t + 1] - tile_ptr_[(size_t)t];
+        }
+        for (int i = tile_ptr_.back(); i < n; ++i) part[(size_t)i] = nparts - 1;
+    } else {
+        vector<int> idx((size_t)n);
+        for (int i = 0; i < n; ++i) idx[(size_t)i] = i;
+        std::sort(idx.begin(), idx.end(), [&](int a2, int b2) { return xof(a2) < xof(b2) || (xof(a2) == xof(b2) && a2 < b2); });
+        for (int k = 0; k < n; ++k) part[(size_t)idx[(size_t)k]] = (int)((long long)k * nparts / n);
+    }
+    return part;
+}
+
+Grid *Grid::extract_subdomain(const vector<int> &part, int rank)
+{
+    if (neumannFlag_) throw std::invalid_argument("extract_subdomain: Dirichlet grids only");
+    const int n = (int)points_.size();
+    if ((int)part.size() != n) throw std::invalid_argument("extract_subdomain: part size mismatch");
+    const int *rp = laplaceMat_->outerIndexPtr();
+    const int *col = laplaceMat_->innerIndexPtr();
+    const double *val = laplaceMat_->valuePtr();
+    vector<int> local((size_t)n, -1), owned;
+    for (int i = 0; i < n; ++i)
+        if (part[(size_t)i] == rank) { local[(size_t)i] = (int)owned.size(); owned.push_back(i); }
+    vector<std::pair<int, int>> ghosts;  // (owner, global index)
+    for (int i : owned)
+        for (int p = rp[i]; p < rp[i + 1]; ++p) {
+            const int c = col[p];
+            if (part[(size_t)c] != rank && local[(size_t)c] == -1) { local[(size_t)c] = -2; ghosts.emplace_back(part[(size_t)c], c); }
+        }
+    std::sort(ghosts.begin(), ghosts.end());
+    const int no = (int)owned.size(), ng = (int)ghosts.size();
+    for (int k = 0; k < ng; ++k) local[(size_t)ghosts[(size_t)k].second] = no + k;
+
+    vector<Point> pts((size_t)(no + ng));
+    VectorXd src((size_t)(no + ng));
+    for (int k = 0; k < no; ++k) { pts[(size_t)k] = points_[(size_t)owned[(size_t)k]]; src(k) = source_.coeff(owned[(size_t)k]); }
+    for (int k = 0; k < ng; ++k) pts[(size_t)(no + k)] = points_[(size_t)ghosts[(size_t)k].second];
+    vector<Boundary> bnds;
+    for (const Boundary &b : boundaries_) {
+        Boundary nb;
+        nb.type = b.type;
+        for (size_t j = 0; j < b.bcPoints.size(); ++j)
+            if (part[(size_t)b.bcPoints[j]] == rank) {
+                nb.bcPoints.push_back(local[(size_t)b.bcPoints[j]]);
+                nb.values.push_back(j < b.values.size() ? b.values[j] : 0.0);
+            }
+        bnds.push_back(nb);
+    }
+    Grid *g = new Grid(pts, bnds, properties_, src);
+    g->dim_ = dim_;
+    g->implicitFlag_ = implicitFlag_;
+    g->lanes_per_row_ = lanes_per_row_;
+    g->tile_size_ = tile_size_;
+    for (int k = 0; k < no; ++k) g->bcFlags_[(size_t)k] = bcFlags_[(size_t)owned[(size_t)k]];
+    for (int k = 0; k < ng; ++k) g->bcFlags_[(size_t)(no + k)] = kGhost;
+    g->nOwned_ = no;
+    g->origIndex_.resize((size_t)(no + ng));
+    for (int k = 0; k < no; ++k) g->origIndex_[(size_t)k] = owned[(size_t)k];
+    for (int k = 0; k < ng; ++k) { g->origIndex_[(size_t)(no + k)] = ghosts[(size_t)k].second; g->ghostOwner_.push_back(ghosts[(size_t)k].first); }
+    // rows of the owned points, columns renumbered (ascending LOCAL order is not required by
+    // libmmgp, but keep the global column order so a row's dot product associates identically)
+    std::vector<int> outer((size_t)(no + ng) + 1, 0), inner;
+    std::vector<double> v;
+    for (int k = 0; k < no; ++k) {
+        const int i = owned[(size_t)k];
+        for (int p = rp[i]; p < rp[i + 1]; ++p) { inner.push_back(local[(size_t)col[p]]); v.push_back(val[p]); }
+        outer[(size_t)k + 1] = (int)inner.size();
+    }
+    for (int k = no; k < no + ng; ++k) outer[(size_t)k + 1] = outer[(size_t)k];
+    delete g->laplaceMat_;
+    g->laplaceMat_ = new SparseRowMajor(no + ng, no + ng, true);
+    g->laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(v));
+    // tiles: the owned part of every global tile, in order
+    if (!tile_ptr_.empty()) {
+        g->tile_ptr_.push_back(0);
+        for (size_t t = 0; t + 1 < tile_ptr_.size(); ++t) {
+            int cnt = 0;
+            for (int i = tile_ptr_[t]; i < tile_ptr_[t + 1]; ++i) cnt += part[(size_t)i] == rank;
+            if (cnt) g->tile_ptr_.push_back(g->tile_ptr_.back() + cnt);
+        }
+        if (g->tile_ptr_.back() != no) g->tile_ptr_.clear();  // points outside every tile: let libmmgp tile uniformly
+    }
+    return g;
 }
 
 // grid.cpp:664-685
@@ -454,6 +563,12 @@ void Grid::apply_order(const vector<int> &order)
         ns[i] = src[o];
         nn[i] = normalVecs_[o];
         old2new[o] = (int)i;
+    }
+    if (origIndex_.empty()) { origIndex_.resize(n); for (size_t i = 0; i < n; ++i) origIndex_[i] = (int)i; }
+    {
+        vector<int> no2(n);
+        for (size_t i = 0; i < n; ++i) no2[i] = origIndex_[(size_t)order[i]];
+        origIndex_.swap(no2);
     }
     points_.swap(np);
     src.swap(ns);

@@ -57,6 +57,13 @@ public:
     int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy
     int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
     int setup_threads_ = 0;      // 0 = hardware concurrency
+    // domain decomposition: bcFlags_ == 3 marks a GHOST point (copy of a point owned by
+    // another rank): searchable as a stencil neighbour, never relaxed, no matrix row.
+    // Owned points come first, ghosts last, grouped by owner.
+    static const int kGhost = 3;
+    int nOwned_ = -1;            // -1: not a sub-domain
+    vector<int> origIndex_;      // global id of every local point (sub-domains) / index before reordering
+    vector<int> ghostOwner_;     // owner rank of ghost k (k-th point after the owned ones)
 
     Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source);
     virtual ~Grid();
@@ -93,6 +100,13 @@ public:
     // Same sparsity/bytes as the RBF-FD Laplacian, no dense solve per point, so
     // 1e7-point clouds can be set up in seconds for bench.py.
     void build_graph_laplacian();
+    // Spatial partition into `nparts` slabs along x with balanced point counts; whole
+    // tiles stay together when mc_order_points() has run.  Returns the owner of every point.
+    vector<int> partition_slabs(int nparts);
+    // The local system of `rank`: its owned points in the current storage order, then the
+    // ghost points its rows reference (sorted by owner, then index); matrix rows, boundary
+    // lists, RHS and tile boundaries restricted accordingly.  Dirichlet grids only.
+    Grid *extract_subdomain(const vector<int> &part, int rank);
 
     vector<Point> pointIDs_to_vector(const vector<int> &pointIDs);
     vector<int> kNearestNeighbors(Point point, bool neumannFlag, bool pointBCFlag, int k);  // grid.cpp:216-260

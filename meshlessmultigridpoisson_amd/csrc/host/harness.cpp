@@ -4,8 +4,11 @@
 // genGmshGridNeumann, :328-343 run_mg_sim, :431-442 testGmshSingleGrid) on
 // clouds handed in by the caller; the drivers themselves (file naming, txt
 // dumps, parameter sweeps) are out of scope.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -309,6 +312,102 @@ void *mmgh_grid_device(void *gp)
 int mmgh_grid_sor_wrong_args(void *gp)  // error behaviour check: foreign vectors are rejected loudly
 {
     return guard([&]() { Grid *g = static_cast<Grid *>(gp); mmgh::Vec other(g->values_->rows()); g->sor(g->laplaceMat_, &other, &g->source_); });
+}
+
+// ---- domain decomposition ----------------------------------------------------------------
+void mmgh_grid_partition_slabs(void *gp, int nparts, int *part)
+{
+    auto p = static_cast<Grid *>(gp)->partition_slabs(nparts);
+    std::memcpy(part, p.data(), sizeof(int) * p.size());
+}
+void *mmgh_grid_extract_subdomain(void *gp, const int *part, int rank)
+{
+    Grid *g = static_cast<Grid *>(gp), *out = nullptr;
+    if (guard([&]() { out = g->extract_subdomain(std::vector<int>(part, part + g->points_.size()), rank); })) return nullptr;
+    return out;
+}
+// n_owned, then gid[n_local] and ghost_owner[n_local - n_owned]
+int mmgh_grid_n_owned(void *gp) { return static_cast<Grid *>(gp)->nOwned_; }
+void mmgh_grid_local_map(void *gp, int *gid, int *ghost_owner)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    std::memcpy(gid, g->origIndex_.data(), sizeof(int) * g->origIndex_.size());
+    std::memcpy(ghost_owner, g->ghostOwner_.data(), sizeof(int) * g->ghostOwner_.size());
+}
+
+// Local system of one rank built WITHOUT ever forming the global one (weak-scaling bench):
+// the caller passes its owned points plus a margin of candidate ghost points.
+//   flags_in: 0 interior, 1 Dirichlet boundary (owned), 3 margin point owned by `owner[i]`
+//   gid     : global id of every point
+// Margin points no owned stencil references are dropped; the rest become ghosts (sorted by
+// owner, then gid).  Operator: graph Laplacian (kind 2) on `stencil` nearest neighbours.
+void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, const int *gid, const int *owner, int dim,
+                             int stencil, int tile_points, int lanes_per_row, double omega, int iters)
+{
+    Grid *out = nullptr;
+    const int rc = guard([&]() {
+        std::vector<Point> pts = to_points(xyz, n);
+        GridProperties props = make_props(3, dim, omega, iters);
+        props.stencilSize = stencil;
+        // pass 1: which margin points are referenced by owned stencils
+        std::vector<char> used((size_t)n, 0);
+        {
+            Grid probe(pts, std::vector<Boundary>(), props, mmgh::Vec((size_t)n));
+            probe.dim_ = dim;
+            std::vector<std::vector<int>> nb((size_t)n);
+            std::vector<int> ownedIdx;
+            for (int i = 0; i < n; ++i) if (flags_in[i] != Grid::kGhost) ownedIdx.push_back(i);
+            probe.kNearestNeighbors(pts[0], false, false, 1);
+            int nth = std::max(1u, std::thread::hardware_concurrency());
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; ++t)
+                th.emplace_back([&]() {
+                    for (;;) {
+                        const size_t b = next.fetch_add(256);
+                        if (b >= ownedIdx.size()) break;
+                        for (size_t k = b; k < std::min(ownedIdx.size(), b + 256); ++k)
+                            for (int j : probe.kNearestNeighbors(pts[(size_t)ownedIdx[k]], false, false, stencil)) used[(size_t)j] = 1;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        std::vector<int> keepOwned, ghosts;
+        for (int i = 0; i < n; ++i) {
+            if (flags_in[i] != Grid::kGhost) keepOwned.push_back(i);
+            else if (used[(size_t)i]) ghosts.push_back(i);
+        }
+        std::sort(ghosts.begin(), ghosts.end(), [&](int a, int b) {
+            return owner[a] < owner[b] || (owner[a] == owner[b] && gid[a] < gid[b]);
+        });
+        const int no = (int)keepOwned.size(), ng = (int)ghosts.size();
+        std::vector<Point> lp;
+        std::vector<int> lgid, lflag;
+        Boundary bnd;
+        bnd.type = 1;
+        for (int k = 0; k < no; ++k) {
+            const int i = keepOwned[(size_t)k];
+            lp.push_back(pts[(size_t)i]);
+            lgid.push_back(gid[i]);
+            lflag.push_back(flags_in[i]);
+            if (flags_in[i] == 1) { bnd.bcPoints.push_back(k); bnd.values.push_back(0.0); }
+        }
+        for (int i : ghosts) { lp.push_back(pts[(size_t)i]); lgid.push_back(gid[i]); lflag.push_back(Grid::kGhost); }
+        Grid *g = new Grid(lp, std::vector<Boundary>(1, bnd), props, mmgh::Vec((size_t)(no + ng)));
+        g->dim_ = dim;
+        g->implicitFlag_ = false;
+        g->lanes_per_row_ = lanes_per_row;
+        g->setBCFlag(0, "dirichlet", bnd.values);
+        for (int k = no; k < no + ng; ++k) g->bcFlags_[(size_t)k] = Grid::kGhost;
+        g->nOwned_ = no;
+        g->origIndex_ = lgid;  // apply_order permutes this along with the points
+        for (int i : ghosts) g->ghostOwner_.push_back(owner[i]);
+        g->mc_order_points(tile_points);
+        g->build_graph_laplacian();
+        out = g;
+    });
+    if (rc) { delete out; return nullptr; }
+    return out;
 }
 
 // ---- leaf functions & file formats ---------------------------------------------------------

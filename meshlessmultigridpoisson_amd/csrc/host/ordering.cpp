@@ -91,7 +91,7 @@ void par_for(int n, int nth, F f)
 void Grid::mc_order_points(int tile_points)
 {
     const int n = (int)points_.size();
-    if (tile_points <= 0) tile_points = mmg_auto_tile_points(n, dim_, properties_.stencilSize, lanes_per_row_, 0, 0);
+    if (tile_points <= 0) tile_points = mmg_auto_tile_points(nOwned_ >= 0 ? nOwned_ : n, dim_, properties_.stencilSize, lanes_per_row_, 0, 0);
     if (tile_points < 8) tile_points = 8;
     ensure_knn();
     const int nth = threads();
@@ -99,6 +99,7 @@ void Grid::mc_order_points(int tile_points)
     // ---- predicted coupling graph (same construction as rcm_order_points) -------
     vector<vector<int>> adj((size_t)n);
     par_for(n, nth, [&](int i) {
+        if (bcFlags_[(size_t)i] == kGhost) return;
         adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
     });
     if (neumannFlag_ && implicitFlag_) {
@@ -121,28 +122,31 @@ void Grid::mc_order_points(int tile_points)
     // index, so the parity colouring (ix%2, iy%2, iz%2) -- 4 colours in 2-D, 8 in
     // 3-D, all equally populated -- is proper whenever a tile is at least one
     // stencil reach wide.  tiling_ == 1 selects kd-tree leaves + greedy colouring.
-    vector<int> idx((size_t)n);
-    std::iota(idx.begin(), idx.end(), 0);
+    // ghost points (sub-domains) are not tiled: they keep their relative order at the end
+    vector<int> idx, ghost_idx;
+    for (int i = 0; i < n; ++i) (bcFlags_[(size_t)i] == kGhost ? ghost_idx : idx).push_back(i);
+    const int n_all = n;
+    const int n_t = (int)idx.size();
     vector<int> bounds;
     vector<int> parity_colour;  // per tile, slab tiling only
     if (tiling_ == 1) {
         KdSplit kd{points_, dim_, tile_points, idx, {}};
-        kd.run(0, n, bounds, 0);
+        kd.run(0, n_t, bounds, 0);
         std::sort(bounds.begin(), bounds.end());
     } else {
         double ext[3] = {1, 1, 1};
         for (int a2 = 0; a2 < dim_; ++a2) {
             double mn = 1e300, mx = -1e300;
-            for (const Point &p : points_) { mn = std::min(mn, comp(p, a2)); mx = std::max(mx, comp(p, a2)); }
+            for (int i : idx) { const Point &p = points_[(size_t)i]; mn = std::min(mn, comp(p, a2)); mx = std::max(mx, comp(p, a2)); }
             ext[a2] = std::max(mx - mn, 1e-300);
         }
-        const double n_leaf = std::max(1.0, (double)n / tile_points);
+        const double n_leaf = std::max(1.0, (double)n_t / tile_points);
         int m[3] = {1, 1, 1};
         double vol = 1.0;
         for (int a2 = 0; a2 < dim_; ++a2) vol *= ext[a2];
         for (int a2 = 0; a2 < dim_; ++a2)
             m[a2] = std::max(1, (int)std::floor(std::pow(n_leaf / vol, 1.0 / dim_) * ext[a2] + 0.5));
-        while ((double)m[0] * m[1] * m[2] * tile_points < (double)n) {  // keep tiles <= tile_points
+        while ((double)m[0] * m[1] * m[2] * tile_points < (double)n_t) {  // keep tiles <= tile_points
             int best = 0;
             for (int a2 = 1; a2 < dim_; ++a2)
                 if (ext[a2] / m[a2] > ext[best] / m[best]) best = a2;
@@ -157,7 +161,7 @@ void Grid::mc_order_points(int tile_points)
         auto cut = [](int lo, int hi, int parts, int k) { return lo + (int)((long long)(hi - lo) * k / parts); };
         std::sort(idx.begin(), idx.end(), by_axis(0));
         vector<std::pair<int, int>> slabs;
-        for (int ix = 0; ix < m[0]; ++ix) slabs.emplace_back(cut(0, n, m[0], ix), cut(0, n, m[0], ix + 1));
+        for (int ix = 0; ix < m[0]; ++ix) slabs.emplace_back(cut(0, n_t, m[0], ix), cut(0, n_t, m[0], ix + 1));
         vector<vector<int>> sb((size_t)m[0]), sc((size_t)m[0]);
         par_for(m[0], nth, [&](int ix) {
             const int lo = slabs[(size_t)ix].first, hi = slabs[(size_t)ix].second;
@@ -180,9 +184,9 @@ void Grid::mc_order_points(int tile_points)
         }
         if (std::getenv("MMG_VERBOSE")) std::fprintf(stderr, "[mc_order_points] slab tiling %d x %d x %d\n", m[0], m[1], m[2]);
     }
-    bounds.push_back(n);
+    bounds.push_back(n_t);
     const int nt = (int)bounds.size() - 1;
-    vector<int> tile_of((size_t)n), pos_in((size_t)n);
+    vector<int> tile_of((size_t)n_all, -1), pos_in((size_t)n_all, 0);
     for (int t = 0; t < nt; ++t)
         for (int k = bounds[(size_t)t]; k < bounds[(size_t)t + 1]; ++k) {
             tile_of[(size_t)idx[(size_t)k]] = t;
@@ -299,6 +303,7 @@ void Grid::mc_order_points(int tile_points)
         order.insert(order.end(), loc.begin(), loc.end());
         tptr.push_back((int)order.size());
     }
+    order.insert(order.end(), ghost_idx.begin(), ghost_idx.end());
     apply_order(order);
     tile_ptr_ = tptr;
 }

@@ -178,3 +178,55 @@ def test_generic_spmv():
     y = m.apply(x)
     ref = A @ x
     assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_rccl_ghost_exchange_single_rank_loopback():
+    """The multi-GPU ghost refresh (mmg_level_exchange: pack kernel + grouped ncclSend/ncclRecv
+    straight into the ghost segment) exercised on one GPU with the rank as its own neighbour:
+    ghosts must become copies of the listed owned points, and a distributed sweep must equal
+    'manual ghost copy + plain sweep'."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi, _host
+    pts, flags, gid, owner = _host.slab_cloud(0, 2, 12, dim=3, margin=5)
+    sub = _host.Grid.create_local(pts, flags, gid, owner, 3, 50, tile_points=256, lanes_per_row=2)
+    n_owned, lgid, gown = sub.local_map()
+    la = sub.level_arrays()
+    n_ghost = la["n"] - n_owned
+    assert n_ghost > 0
+    rng = np.random.default_rng(9)
+    x0 = rng.standard_normal(la["a_size"])
+    b0 = rng.standard_normal(la["a_size"])
+    b0[n_owned:] = 0.0
+    send_idx = rng.integers(0, n_owned, size=n_ghost).astype(np.int32)
+
+    def make():
+        return _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], 0, 1.4, 5, la["btype"], la["bptr"],
+                           la["bpts"], la["bvals"], x=x0, b=b0, tile_ptr=sub.tile_ptr(), lanes_per_row=2)
+
+    _capi.comm_init(0, 1, _capi.comm_unique_id())
+    try:
+        d = make()
+        d.set_exchange(n_owned, [0], [0, n_ghost], send_idx, [0, n_ghost])
+        d.exchange()
+        x = d.get_x()
+        assert np.array_equal(x[n_owned:], x0[send_idx]) and np.array_equal(x[:n_owned], x0[:n_owned])
+        d.sweeps(2)
+        m = make()
+        for _ in range(2):
+            xm = m.get_x()
+            xm[n_owned:] = xm[send_idx]
+            m.set_x(xm)
+            m.sweeps(1)
+        assert np.array_equal(d.get_x(), m.get_x())
+        # oracle cross-check of one local sweep with frozen ghosts
+        o = H.oracle_level(dict(la, x0=x0, b0=b0))
+        o.x[n_owned:] = o.x[send_idx]
+        o.sor_sweeps(1)
+        m2 = make()
+        xm = m2.get_x()
+        xm[n_owned:] = xm[send_idx]
+        m2.set_x(xm)
+        m2.sweeps(1)
+        assert H.rel_err(m2.get_x(), o.x) < 1e-12
+    finally:
+        _capi.comm_finalize()
