@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2, help="lanes per row of the sweep kernel")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--persistent", type=int, default=0, help="1: one dependency-driven launch per sweep")
     return ap.parse_args()
 
 
@@ -91,6 +92,7 @@ def main():
     if _capi.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (libmmgp has no CPU fallback)")
     _capi.check(_capi.lib().mmg_set_device(local_rank))
+    _capi.set_option("persistent_sweep", a.persistent)
 
     # ---- setup (untimed): cloud -> ordering -> operator -> packed device layout ----
     t_setup = time.perf_counter()
@@ -159,6 +161,7 @@ def main():
         total_points = float(interior)
 
     # dominant kernel: per-launch HIP events on the library's stream
+    _capi.set_option("persistent_sweep", 0)  # per-phase launches for the per-kernel roofline figure
     kern_ms, launches = lv.time_phases(max(2, min(a.steps, 10)))
     sweeps_timed = max(2, min(a.steps, 10))
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
@@ -185,7 +188,7 @@ def main():
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
                 "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
-                "lds_bytes_per_wave": info["max_lds_bytes"],
+                "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": a.persistent,
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if world == 1 else
                                f"domain decomposition: {world} x-slabs, RCCL ghost exchange once per sweep "

@@ -91,6 +91,12 @@ int mmg_set_device(int device);
  * thread's handles; NULL selects the library's own non-blocking stream. */
 int mmg_set_stream(void *hip_stream);
 int mmg_synchronize(void);
+/* "persistent_sweep" (0/1): relax a level with ONE launch per sweep -- resident
+ * wavefronts draw tiles in phase order and start each as soon as the earlier tiles
+ * it is coupled to have published their values -- instead of one launch per phase.
+ * Same arithmetic, same order of coupled rows (exact); removes the per-phase
+ * ramp-up/tail. */
+int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);
 /* Tile size (points per tile) for Grid::mc_order_points: the largest tile whose

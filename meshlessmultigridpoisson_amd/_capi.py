@@ -38,7 +38,7 @@ class LevelInfo(C.Structure):
 #: every symbol include/mmgp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
-    "mmg_device_props", "mmg_auto_tile_points", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
+    "mmg_device_props", "mmg_auto_tile_points", "mmg_set_option", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
     "mmg_level_set_exchange", "mmg_level_exchange",
     "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
@@ -101,6 +101,7 @@ def lib():
         L.mmg_set_device.argtypes = [C.c_int]
         L.mmg_device_count.argtypes = [_ip]
         L.mmg_device_props.argtypes = [_ip, _ip]
+        L.mmg_set_option.argtypes = [C.c_char_p, C.c_int]
         L.mmg_comm_get_unique_id.argtypes = [C.c_char_p]
         L.mmg_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p]
         L.mmg_level_set_exchange.argtypes = [vp, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
@@ -132,6 +133,10 @@ def comm_init(rank, nranks, id128):
 
 def comm_finalize():
     check(lib().mmg_comm_finalize())
+
+
+def set_option(name, value):
+    check(lib().mmg_set_option(name.encode(), int(value)))
 
 
 def device_props():

@@ -24,6 +24,7 @@ using namespace mmg;
 namespace {
 
 thread_local std::string g_err;
+bool g_persistent_sweep = false;  // mmg_set_option("persistent_sweep", 1)
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
 
@@ -137,6 +138,7 @@ struct PlanGpu {
     DevBuf<uint32_t> ghead;
     DevBuf<uint8_t> stream;
     DevBuf<int32_t> phase_tiles;
+    DevBuf<int32_t> dep_ptr, dep_idx;
     std::vector<int32_t> phase_ptr;
     PlanDev dev;
     int n_tiles = 0;
@@ -152,6 +154,10 @@ struct PlanGpu {
         HIPC(ghead.upload(P.ghead.data(), P.ghead.size()));
         HIPC(stream.upload(P.stream.data(), P.stream.size()));
         HIPC(phase_tiles.upload(P.phase_tiles.data(), P.phase_tiles.size()));
+        HIPC(dep_ptr.upload(P.dep_ptr.data(), P.dep_ptr.size()));
+        HIPC(dep_idx.upload(P.dep_idx.data(), P.dep_idx.size()));
+        dev.dep_ptr = dep_ptr.p;
+        dev.dep_idx = dep_idx.p;
         phase_ptr = P.phase_ptr;
         n_tiles = P.n_tiles;
         n_rows = P.n_rows;
@@ -195,6 +201,10 @@ struct mmg_level {
     DevBuf<double> dir_vals, neu_vals;
     DevBuf<double> partA, partX, partB, partBn, scal;
     int n_absb = 0;
+    // dependency-driven single-launch sweep
+    DevBuf<unsigned> sync_words;  // [0] ticket, [1] error, [2..] done flag per tile
+    unsigned epoch = 0;
+    int workers = 0;
     // domain decomposition (mmg_level_set_exchange)
     bool distributed = false;
     int n_owned = 0;
@@ -262,13 +272,35 @@ int sweep_once(mmg_level *lv)
     a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
     a.flags8 = lv->flags8.p;
     a.partial = lv->neumann ? lv->partX.p : nullptr;
-    for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
-        a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
-        a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
-        HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+    if (g_persistent_sweep && lv->A.n_phases() > 1 && lv->workers > 0) {
+        // one launch: tiles in phase order, started by their dependencies (kernels.hip)
+        a.tile_list = lv->A.dev.phase_tiles;
+        a.n_list = lv->A.n_tiles;
+        a.ticket = lv->sync_words.p;
+        a.error = lv->sync_words.p + 1;
+        a.done = lv->sync_words.p + 2;
+        a.epoch = ++lv->epoch;
+        HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
+        HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
+    } else {
+        for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
+            a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
+            a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+            HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+        }
     }
     if (lv->neumann)
         HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+    return MMG_OK;
+}
+
+int check_sync_error(mmg_level *lv)
+{
+    if (!lv->sync_words.p || lv->epoch == 0) return MMG_OK;
+    unsigned e = 0;
+    HIPC(hipMemcpyAsync(&e, lv->sync_words.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    if (e) return fail(MMG_ERR_HIP, "persistent sweep: a tile dependency wait timed out");
     return MMG_OK;
 }
 
@@ -494,6 +526,13 @@ int mmg_set_stream(void *hip_stream)
     return MMG_OK;
 }
 
+int mmg_set_option(const char *name, int value)
+{
+    if (!name) return fail(MMG_ERR_INVALID, "null option");
+    if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value != 0; return MMG_OK; }
+    return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
+}
+
 int mmg_synchronize(void)
 {
     int rc = ensure_device();
@@ -622,6 +661,16 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     lv->n_absb = abs_sum_blocks(d->a_size);
     HIPC(lv->partBn.alloc((size_t)std::max(1, lv->n_absb)));
     HIPC(lv->scal.alloc(2));
+    HIPC(lv->sync_words.alloc((size_t)lv->A.n_tiles + 2));
+    HIPC(hipMemset(lv->sync_words.p, 0, sizeof(unsigned) * lv->sync_words.n));
+    {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        HIPC(hipGetDevice(&dev));
+        HIPC(hipGetDeviceProperties(&prop, dev));
+        HIPC(sweep_persistent_blocks_per_cu(lv->A.dev, &per_cu));
+        lv->workers = per_cu * prop.multiProcessorCount;
+    }
     HIPC(hipMemset(lv->partA.p, 0, sizeof(double) * lv->partA.n));
     HIPC(hipMemset(lv->partX.p, 0, sizeof(double) * lv->partX.n));
     HIPC(hipMemset(lv->partB.p, 0, sizeof(double) * lv->partB.n));
@@ -660,6 +709,7 @@ LEVEL_VEC_IO(mmg_level_set_x, x, const)
     return MMG_OK;
 }
 LEVEL_VEC_IO(mmg_level_get_x, x, )
+    if ((rc = check_sync_error(lv))) return rc;
     HIPC(hipMemcpyAsync(v, lv->x.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;

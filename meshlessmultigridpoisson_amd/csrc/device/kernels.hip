@@ -87,22 +87,29 @@ __device__ __forceinline__ unsigned slot_of(const uint2 &s, int k)
     return (k & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+// x accesses of the dependency-driven sweep go through agent-scope relaxed atomics
+// (global_load/store ... sc1): L2-served, never stale in another CU's L1
+// (MI355X_MICROARCH "Workgroup dispatch ... inter-workgroup visibility").
+template <bool SC1>
+__device__ __forceinline__ double ld_x(const double *p)
+{
+    if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool SC1>
+__device__ __forceinline__ void st_x(double *p, double v)
+{
+    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // One wavefront per tile.  LDS: xs[n_slots] (inputs) | bs[n_own] (rhs of the own
 // range, SOR/RESID) | gh[n_groups] (group heads).
-template <int L, int MODE, int MAXP>
-__global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
+template <int L, int MODE, int MAXP, bool SC1>
+__device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, unsigned char *smem, const double lam)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
     double *xs = reinterpret_cast<double *>(smem);
     const int lane = threadIdx.x;
-
-    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch),
-    // so XCD k walks the contiguous tile range [k*per, (k+1)*per): neighbouring
-    // tiles -- which share halo lines -- hit the same 4 MiB L2.
-    const int per = (a.n_list + 7) >> 3;
-    const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (idx >= a.n_list) return;
-    const int tile = a.tile_list ? a.tile_list[idx] : idx;
     const TileDesc td = a.p.tiles[tile];
     const uint32_t n_own = td.n_own, n_halo = td.n_halo, n_groups = td.n_groups;
     const uint32_t n_slots = n_own + n_halo + 1;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
         for (int k = 0; k < 8; ++k) {
             const uint32_t i = base + k * 64 + lane;
             const uint32_t ii = i < n_own ? i : n_own - 1;
-            tx[k] = in[td.row0 + ii];
+            tx[k] = ld_x<SC1>(in + td.row0 + ii);
             if (kUsesB) tb[k] = a.b[td.row0 + ii];
         }
 #pragma unroll
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
             ti[k] = hl[i < n_halo ? i : n_halo - 1];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tx[k] = in[ti[k]];
+        for (int k = 0; k < 8; ++k) tx[k] = ld_x<SC1>(in + ti[k]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t i = base + k * 64 + lane;
@@ -151,9 +158,6 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
         }
     }
     if (lane == 0) xs[n_slots - 1] = 0.0;
-    double lam = 0.0;
-    if (MODE == MODE_SOR || MODE == MODE_RESID)
-        if (a.lambda) lam = *a.lambda;
 
     const unsigned char *p = a.p.stream + td.stream_off;
     GroupRegs<MAXP> ra, rb;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
         double s = 0.0;
         for (uint32_t i = lane; i < n_own; i += 64) {
             const double v = xs[i];
-            a.out[td.row0 + i] = v;
+            st_x<SC1>(a.out + td.row0 + i, v);
             if (a.partial && a.flags8[td.row0 + i] < 2) s += v;
         }
         if (a.partial) {
@@ -244,6 +248,67 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
             s = wave_sum(s);
             if (lane == 0) a.partial2[tile] = s;
         }
+    }
+}
+
+template <int L, int MODE, int MAXP>
+__global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch),
+    // so XCD k walks the contiguous tile range [k*per, (k+1)*per): neighbouring
+    // tiles -- which share halo lines -- hit the same 4 MiB L2.
+    const int per = (a.n_list + 7) >> 3;
+    const int idx = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (idx >= a.n_list) return;
+    const int tile = a.tile_list ? a.tile_list[idx] : idx;
+    double lam = 0.0;
+    if (MODE == MODE_SOR || MODE == MODE_RESID)
+        if (a.lambda) lam = *a.lambda;
+    process_tile<L, MODE, MAXP, false>(a, tile, smem, lam);
+}
+
+// Dependency-driven sweep: ONE launch per sweep.  Resident wavefronts draw tiles from a
+// ticket counter in phase order; a tile starts as soon as the (<= ~26) earlier tiles it
+// is coupled to have published their x values, so the ramp-up, the tail and the input
+// staging of consecutive phases overlap instead of being separated by kernel boundaries.
+// Progress: a ticket holder only waits for tiles with smaller tickets, whose holders are
+// running -- no co-residency requirement, no grid barrier.  Visibility: x is written with
+// sc1 stores, drained (vmcnt(0)), released at agent scope, then the tile's flag is stored;
+// the consumer polls relaxed, acquires once at agent scope, and reads x with sc1 loads.
+template <int L, int MAXP>
+__global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    double lam = 0.0;
+    if (a.lambda) lam = *a.lambda;
+    for (;;) {
+        unsigned q = 0;
+        if (lane == 0) q = atomicAdd(a.ticket, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= (unsigned)a.n_list) break;
+        const int tile = a.tile_list[q];
+        const int d0 = a.p.dep_ptr[tile], d1 = a.p.dep_ptr[tile + 1];
+        for (int base = d0; base < d1; base += 64) {
+            const int k = base + lane;
+            const unsigned *flag = a.done + (k < d1 ? a.p.dep_idx[k] : tile);
+            bool ok = !(k < d1);
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!__all(ok) && lane == 0) atomicOr(a.error, 1u);  // never hang: report and go on
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        process_tile<L, MODE_SOR, MAXP, true>(a, tile, smem, lam);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.done + tile, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();  // LDS of this tile is dead before the next one is staged
     }
 }
 
@@ -273,6 +338,23 @@ hipError_t launch_L(TileMode mode, const TileArgs &a, hipStream_t s)
     if (mp <= 28) return launch_LP<L, 28>(mode, a, s);
     if (mp <= 64) return launch_LP<L, 64>(mode, a, s);
     return hipErrorInvalidValue;  // build_plan caps plen (kMaxPlen)
+}
+
+template <int L, int MAXP>
+hipError_t launch_persist_LP(const TileArgs &a, int workers, hipStream_t s)
+{
+    hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP>), dim3((unsigned)workers), dim3(64), a.p.lds_bytes, s, a);
+    return hipGetLastError();
+}
+template <int L>
+hipError_t launch_persist_L(const TileArgs &a, int workers, hipStream_t s)
+{
+    const int mp = a.p.max_plen;
+    if (mp <= 8) return launch_persist_LP<L, 8>(a, workers, s);
+    if (mp <= 16) return launch_persist_LP<L, 16>(a, workers, s);
+    if (mp <= 28) return launch_persist_LP<L, 28>(a, workers, s);
+    if (mp <= 64) return launch_persist_LP<L, 64>(a, workers, s);
+    return hipErrorInvalidValue;
 }
 
 // ---- small kernels -------------------------------------------------------------
@@ -380,6 +462,45 @@ hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s)
     case 16: return launch_L<16>(mode, a, s);
     case 32: return launch_L<32>(mode, a, s);
     case 64: return launch_L<64>(mode, a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int L>
+hipError_t occ_L(const PlanDev &p, int *blocks)
+{
+    const int mp = p.max_plen;
+    if (mp <= 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 8>, 64, p.lds_bytes);
+    if (mp <= 16) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 16>, 64, p.lds_bytes);
+    if (mp <= 28) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 28>, 64, p.lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 64>, 64, p.lds_bytes);
+}
+
+hipError_t sweep_persistent_blocks_per_cu(const PlanDev &p, int *blocks)
+{
+    switch (p.L) {
+    case 1: return occ_L<1>(p, blocks);
+    case 2: return occ_L<2>(p, blocks);
+    case 4: return occ_L<4>(p, blocks);
+    case 8: return occ_L<8>(p, blocks);
+    case 16: return occ_L<16>(p, blocks);
+    case 32: return occ_L<32>(p, blocks);
+    case 64: return occ_L<64>(p, blocks);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_sweep_persistent(const TileArgs &a, int workers, hipStream_t s)
+{
+    if (a.n_list <= 0 || workers <= 0) return hipSuccess;
+    switch (a.p.L) {
+    case 1: return launch_persist_L<1>(a, workers, s);
+    case 2: return launch_persist_L<2>(a, workers, s);
+    case 4: return launch_persist_L<4>(a, workers, s);
+    case 8: return launch_persist_L<8>(a, workers, s);
+    case 16: return launch_persist_L<16>(a, workers, s);
+    case 32: return launch_persist_L<32>(a, workers, s);
+    case 64: return launch_persist_L<64>(a, workers, s);
     }
     return hipErrorInvalidValue;
 }

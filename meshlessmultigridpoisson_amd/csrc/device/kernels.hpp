@@ -16,6 +16,8 @@ struct PlanDev {
     int n_tiles = 0;
     unsigned lds_bytes = 0;
     int max_plen = 0;
+    const int32_t *dep_ptr = nullptr;  // in-place plans
+    const int32_t *dep_idx = nullptr;
 };
 
 enum TileMode {
@@ -38,9 +40,20 @@ struct TileArgs {
     const uint8_t *flags8;     // bcFlags per point (partial sums)
     double *partial;           // per tile: SOR: sum of non-Neumann own x; RESID: sum |r|
     double *partial2;          // RESID: sum of non-Neumann own x
+    // dependency-driven single-launch sweep (launch_sweep_persistent)
+    unsigned *ticket;          // work-queue head, zeroed before the launch
+    unsigned *done;            // per tile: epoch of the last completed sweep
+    unsigned epoch;
+    unsigned *error;           // set when a dependency wait times out
 };
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
+
+// one launch per sweep: `workers` resident wavefronts pull tiles in phase order and wait
+// for their coupled earlier tiles through agent-scope flags
+hipError_t launch_sweep_persistent(const TileArgs &a, int workers, hipStream_t s);
+// resident workgroups per CU of the persistent sweep kernel for this plan (occupancy API)
+hipError_t sweep_persistent_blocks_per_cu(const PlanDev &p, int *blocks);
 
 hipError_t launch_fill(double *v, long long n, double c, hipStream_t s);
 hipError_t launch_gather(double *dst, const double *src, const int32_t *idx, int n, hipStream_t s);

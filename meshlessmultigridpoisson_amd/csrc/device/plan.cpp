@@ -316,11 +316,16 @@ std::string build_plan(const PlanSpec &s, Plan *out)
                 else if (u > t) dep[u].push_back(t);
             }
         }
+        P.dep_ptr.assign((size_t)s.n_tiles + 1, 0);
         for (int t = 0; t < s.n_tiles; ++t) {
             int ph = 0;
             for (int32_t u : dep[t]) ph = std::max(ph, phase[u] + 1);
             phase[t] = ph;
             n_phases = std::max(n_phases, ph + 1);
+            std::sort(dep[t].begin(), dep[t].end());
+            dep[t].erase(std::unique(dep[t].begin(), dep[t].end()), dep[t].end());
+            P.dep_idx.insert(P.dep_idx.end(), dep[t].begin(), dep[t].end());
+            P.dep_ptr[(size_t)t + 1] = (int32_t)P.dep_idx.size();
         }
     }
     P.phase_ptr.assign(n_phases + 1, 0);

@@ -230,3 +230,50 @@ def test_rccl_ghost_exchange_single_rank_loopback():
         assert H.rel_err(m2.get_x(), o.x) < 1e-12
     finally:
         _capi.comm_finalize()
+
+
+@pytest.mark.parametrize("name", ["dirichlet_3level", "neumann_3level"])
+@pytest.mark.parametrize("tile,L", [(64, 4), (32, 2), (200, 8)])
+def test_persistent_single_launch_sweep_matches_oracle(name, tile, L):
+    """mmg_set_option("persistent_sweep", 1): one launch per sweep, tiles started by their
+    dependencies through agent-scope flags.  Same coupled-row order => same iterates."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    la = H.level_arrays(case, case["nlevels"] - 1)
+    o = H.oracle_level(la)
+    _capi.set_option("persistent_sweep", 1)
+    try:
+        d = H.device_level(la, tile_size=tile, lanes_per_row=L)
+        assert d.info()["n_phases"] > 1
+        o.boundary_op(0)
+        d.boundary_op(0)
+        for _ in range(3):
+            o.sor_sweeps(2)
+            d.sweeps(2)
+            assert H.rel_err(d.get_x(), o.x) < 1e-12
+        assert abs(d.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio()
+    finally:
+        _capi.set_option("persistent_sweep", 0)
+
+
+def test_persistent_sweep_3d_many_tiles():
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi, _host
+    pts = _host.box_cloud(40, 3, seed=3)
+    g = _host.Grid.create_square(pts, 3, dim=3, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC, tile_points=128,
+                                 lanes_per_row=2)
+    la = g.level_arrays()
+    rng = np.random.default_rng(2)
+    la["b0"] = rng.standard_normal(la["a_size"])
+    o = H.oracle_level(la)
+    _capi.set_option("persistent_sweep", 1)
+    try:
+        d = _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], 0, 1.4, 5, la["btype"], la["bptr"],
+                        la["bpts"], la["bvals"], x=la["x0"], b=la["b0"], tile_ptr=g.tile_ptr(), lanes_per_row=2)
+        assert d.info()["n_tiles"] > 400
+        o.sor_sweeps(4)
+        d.sweeps(4)
+        assert H.rel_err(d.get_x(), o.x) < 1e-12
+    finally:
+        _capi.set_option("persistent_sweep", 0)
