@@ -48,7 +48,10 @@ def parse():
     ap.add_argument("--lanes", type=int, default=2, help="lanes per row of the sweep kernel")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--persistent", type=int, default=0, help="1: one dependency-driven launch per sweep")
+    ap.add_argument("--persistent", type=int, default=1,
+                    help="0: one launch per phase; 1: one dependency-driven launch per sweep; 2: same with agent fences")
+    ap.add_argument("--verify", type=int, default=0,
+                    help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
     return ap.parse_args()
 
 
@@ -143,6 +146,20 @@ def main():
             torch.cuda.synchronize()
         _capi.check(_capi.lib().mmg_synchronize())
 
+    verify = None
+    if a.verify > 0 and a.persistent:
+        x0 = lv.get_x()
+        _capi.set_option("persistent_sweep", 0)
+        lv.sweeps(a.verify)
+        xa = lv.get_x()
+        lv.set_x(x0)
+        _capi.set_option("persistent_sweep", a.persistent)
+        lv.sweeps(a.verify)
+        xb = lv.get_x()
+        verify = {"sweeps": a.verify, "bitwise_equal": bool(np.array_equal(xa, xb)),
+                  "max_abs_diff": float(np.abs(xa - xb).max())}
+        lv.set_x(x0)
+
     lv.sweeps(a.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -161,7 +178,6 @@ def main():
         total_points = float(interior)
 
     # dominant kernel: per-launch HIP events on the library's stream
-    _capi.set_option("persistent_sweep", 0)  # per-phase launches for the per-kernel roofline figure
     kern_ms, launches = lv.time_phases(max(2, min(a.steps, 10)))
     sweeps_timed = max(2, min(a.steps, 10))
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
@@ -198,11 +214,14 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "tile_kernel<L,MODE_SOR>", "launches": launches,
+                "kernel": "sweep_persistent_kernel<L,MAXP>" if a.persistent else "tile_kernel<L,MODE_SOR,MAXP>",
+                "launches": launches,
                 "avg_launch_us": kern_ms * 1e3 / launches,
                 "algorithmic_bytes_per_row": b_sor(stencil),
             },
         }
+        if verify is not None:
+            out["config"]["persistent_vs_phase_launches"] = verify
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(grid, stencil, a.cpu_seconds)
         print(json.dumps(out))

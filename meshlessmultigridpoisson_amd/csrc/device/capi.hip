@@ -24,7 +24,7 @@ using namespace mmg;
 namespace {
 
 thread_local std::string g_err;
-bool g_persistent_sweep = false;  // mmg_set_option("persistent_sweep", 1)
+int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", 0|1|2); 1 = default
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
 
@@ -280,6 +280,7 @@ int sweep_once(mmg_level *lv)
         a.error = lv->sync_words.p + 1;
         a.done = lv->sync_words.p + 2;
         a.epoch = ++lv->epoch;
+        a.fence = g_persistent_sweep == 2;
         HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
         HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
     } else {
@@ -529,7 +530,7 @@ int mmg_set_stream(void *hip_stream)
 int mmg_set_option(const char *name, int value)
 {
     if (!name) return fail(MMG_ERR_INVALID, "null option");
-    if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value != 0; return MMG_OK; }
+    if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -810,7 +811,8 @@ int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
 int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches)
 {
     if (!lv || !kernel_ms || !launches || nsweeps < 1) return fail(MMG_ERR_INVALID, "bad argument");
-    const int nph = lv->A.n_phases();
+    const bool persist = g_persistent_sweep && lv->A.n_phases() > 1 && lv->workers > 0;
+    const int nph = persist ? 1 : lv->A.n_phases();
     const int total = nph * nsweeps;
     std::vector<hipEvent_t> ev((size_t)total * 2);
     for (auto &e : ev) HIPC(hipEventCreate(&e));
@@ -825,17 +827,34 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
     a.partial = lv->neumann ? lv->partX.p : nullptr;
     int k = 0;
     for (int it = 0; it < nsweeps; ++it) {
-        for (int ph = 0; ph < nph; ++ph) {
-            a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
-            a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+        int rc = exchange(lv);
+        if (rc) return rc;
+        if (persist) {
+            a.tile_list = lv->A.dev.phase_tiles;
+            a.n_list = lv->A.n_tiles;
+            a.ticket = lv->sync_words.p;
+            a.error = lv->sync_words.p + 1;
+            a.done = lv->sync_words.p + 2;
+            a.epoch = ++lv->epoch;
+            a.fence = g_persistent_sweep == 2;
+            HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
             HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
-            HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+            HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
             HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
             ++k;
+        } else {
+            for (int ph = 0; ph < nph; ++ph) {
+                a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
+                a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+                HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
+                HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+                HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
+                ++k;
+            }
         }
         if (lv->neumann)
             HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
-        int rc = bound_eval(lv);
+        rc = bound_eval(lv);
         if (rc) return rc;
     }
     HIPC(hipStreamSynchronize(g_stream));
@@ -848,7 +867,7 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
     for (auto &e : ev) (void)hipEventDestroy(e);
     *kernel_ms = (float)sum;
     *launches = total;
-    return MMG_OK;
+    return check_sync_error(lv);
 }
 
 int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out)

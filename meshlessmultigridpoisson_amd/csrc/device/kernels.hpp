@@ -45,6 +45,7 @@ struct TileArgs {
     unsigned *done;            // per tile: epoch of the last completed sweep
     unsigned epoch;
     unsigned *error;           // set when a dependency wait times out
+    int fence;                 // 1: add agent-scope acquire/release fences around every tile
 };
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
