@@ -48,13 +48,14 @@ def main():
         fm = sum(fetch[k]) / len(fetch[k])
         wm = sum(write[k]) / len(write[k])
         mb = (2 * fm + wm) * 1024 / 1e6
-        if "tile_kernel" in k and (traffic is None or mb > traffic):
+        if ("tile_kernel" in k or "sweep_persistent" in k) and (traffic is None or mb > traffic):
             traffic = mb
         lines.append(f"| `{k[:70]}` | {fm:.0f} | {wm:.0f} | {mb:.1f} |")
     if bench:
         rl = bench["roofline"]
         cfg = bench["config"]
-        rows_per_launch = cfg["interior_points_per_gpu"] / cfg["phases_per_sweep"]
+        per_sweep = 1 if cfg.get("persistent_sweep") else cfg["phases_per_sweep"]
+        rows_per_launch = cfg["interior_points_per_gpu"] / per_sweep
         alg = rows_per_launch * rl["algorithmic_bytes_per_row"] / 1e6
         lines += ["", f"bench line: {bench['value']:.0f} {bench['unit']}, {bench['ms_per_step']:.3f} ms/sweep, "
                       f"roofline {rl['achieved']:.0f} GB/s = {rl['frac']*100:.1f} % of {rl['peak']:.0f} GB/s; "
