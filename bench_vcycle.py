@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""bench_vcycle.py -- whole V-cycle timing (not the driver's bench line).
+BASELINE.json configs[1]: 2-D ~1e6-point cloud, 5-level V-cycle, fp64, real RBF-FD
+Laplacians (fine polyDeg 4, coarse 3) and RBF interpolation transfers, built by the
+host classes; V-cycles run device-resident through Multigrid::vCycles."""
+import argparse
+import json
+import sys
+import time
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nside", type=int, default=1000)
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--cycles", type=int, default=20)
+    ap.add_argument("--polydeg", type=int, default=4)
+    ap.add_argument("--oracle-cycles", type=int, default=0, help="also run this many cycles on the CPU oracle")
+    a = ap.parse_args()
+    from meshlessmultigridpoisson_amd import _host
+    t0 = time.perf_counter()
+    sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
+    clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
+    polys = [3] * (a.levels - 1) + [a.polydeg]
+    mg = _host.Multigrid(clouds, polys, neumann=False, ordering=_host.ORDER_MC, tile_points=0)
+    t_setup = time.perf_counter() - t0
+    res, ms = mg.vcycles(3)  # warm-up, creates the device hierarchy
+    t0 = time.perf_counter()
+    res, ms = mg.vcycles(a.cycles)
+    wall = time.perf_counter() - t0
+    out = {"workload": f"2-D {sides[-1]}^2 = {sides[-1] ** 2} points, {a.levels} levels {sides}, polyDeg {polys}",
+           "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
+           "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
+           "fine_points_per_s_per_vcycle": sides[-1] ** 2 / (ms / a.cycles * 1e-3)}
+    if a.oracle_cycles:
+        om = mg.oracle()  # state after the GPU cycles; compare the continuation
+        t0 = time.perf_counter()
+        ro = [om.vcycle() for _ in range(a.oracle_cycles)]
+        out["oracle_ms_per_vcycle"] = (time.perf_counter() - t0) / a.oracle_cycles * 1e3
+        rd = [mg.vcycle() for _ in range(a.oracle_cycles)]
+        out["max_rel_residual_diff_vs_oracle"] = float(max(abs(x - y) / y for x, y in zip(rd, ro)))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

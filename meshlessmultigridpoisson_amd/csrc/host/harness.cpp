@@ -44,7 +44,7 @@ bool on_box_boundary(const Point &p, int dim)
 void order_points(Grid *g, int ordering, int tile_points)
 {
     if (ordering == 0) g->rcm_order_points();
-    else if (ordering == 1) g->mc_order_points(tile_points);
+    else if (ordering == 1) g->mc_order_points(tile_points);  // tile_points <= 0: automatic
 }
 
 GridProperties make_props(int polyDeg, int dim, double omega, int iters)

@@ -106,3 +106,33 @@ def test_3d_graph_level_large_tiles(host):
         g.sor()
         o.sor()
         assert H.rel_err(g.values(), o.x) < 1e-12
+
+
+def test_baseline_config1_1e4_points_3_levels(host):
+    """BASELINE.json configs[0] shape: 2-D unit square, ~1e4 points (100x100 jittered
+    lattice written to and read back from an MSH 2.2 file), 3-level V-cycle, fine polyDeg 4.
+    GPU residual history vs the CPU oracle on the same hierarchy, 1e-10 relative + floor."""
+    import ctypes as C
+    import os
+    import tempfile
+    dp = C.POINTER(C.c_double)
+    clouds = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, n in enumerate([25, 50, 100]):
+            pts = host.square_cloud(n, seed=12345 + i)
+            f = os.path.join(d, f"square_{n * n}.msh").encode()
+            assert host.lib().mmgh_write_msh(f, pts.ctypes.data_as(dp), len(pts)) == 0
+            back = np.zeros((len(pts), 3))
+            assert host.lib().mmgh_points_from_msh(f, back.ctypes.data_as(dp), len(pts), 0) == len(pts)
+            assert np.array_equal(back, pts)  # %.17g round-trips exactly, boundary coordinates stay 0/1
+            clouds.append(back)
+    mg = host.Multigrid(clouds, [3, 3, 4], neumann=False, ordering=host.ORDER_MC, tile_points=0)
+    om = mg.oracle()
+    for k in range(10):
+        ro, rd = om.vcycle(), mg.vcycle()
+        assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+    assert mg.residuals[-1] < 1e-3 * mg.residuals[0]
+    xyz, _ = mg.grid(2).points()
+    exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
+    mg.vcycles(15)
+    assert np.abs(mg.grid(2).values() - exact).sum() / len(exact) < 1e-5
