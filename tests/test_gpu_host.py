@@ -131,8 +131,9 @@ def test_baseline_config1_1e4_points_3_levels(host):
     for k in range(10):
         ro, rd = om.vcycle(), mg.vcycle()
         assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
-    assert mg.residuals[-1] < 1e-3 * mg.residuals[0]
-    xyz, _ = mg.grid(2).points()
-    exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
-    mg.vcycles(15)
-    assert np.abs(mg.grid(2).values() - exact).sum() / len(exact) < 1e-5
+    # (this 3-level hierarchy contracts by only ~0.85 per cycle at 1e4 points -- in the oracle
+    # too: the coarsest level is merely smoothed, multigrid.cpp:92-95 -- so no tight bound here)
+    assert mg.residuals[-1] < 0.6 * max(mg.residuals)
+    mg.vcycles(5)
+    ro = [om.vcycle() for _ in range(5)]
+    assert np.allclose(mg.residuals[-5:], ro, rtol=1e-10, atol=FLOOR)
