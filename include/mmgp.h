@@ -95,7 +95,13 @@ int mmg_synchronize(void);
  * wavefronts draw tiles in phase order and start each as soon as the earlier tiles
  * it is coupled to have published their values -- instead of one launch per phase.
  * Same arithmetic, same order of coupled rows (exact); removes the per-phase
- * ramp-up/tail. */
+ * ramp-up/tail.
+ * "exact_arithmetic" (0/1), affects levels/transfers created AFTERWARDS: validation mode
+ * in which every row is accumulated by one lane in the reference's stored order with
+ * separately rounded multiply/add and the norms/multiplier row are summed sequentially:
+ * iterates and residual histories are then bitwise those of the sequential CPU loops
+ * (grid.cpp:104-151, multigrid.cpp:62-115).  Slow; proves the schedule is the
+ * reference's Gauss-Seidel order. */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);

@@ -24,6 +24,7 @@ using namespace mmg;
 namespace {
 
 thread_local std::string g_err;
+bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created afterwards use the exact kernels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", 0|1|2); 1 = default
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
@@ -144,6 +145,7 @@ struct PlanGpu {
     int n_tiles = 0;
     long long n_rows = 0, n_nnz = 0, n_groups = 0, stream_bytes = 0, halo_entries = 0;
     int max_lds = 0;
+    bool exact = false;
     bool empty() const { return n_rows == 0; }
     int n_phases() const { return (int)phase_ptr.size() - 1; }
 
@@ -178,6 +180,11 @@ struct PlanGpu {
         return MMG_OK;
     }
 };
+
+hipError_t run_tiles(const PlanGpu &pl, TileMode mode, const TileArgs &a, hipStream_t s)
+{
+    return pl.exact ? launch_tile_kernel_exact(mode, a, s) : launch_tile_kernel(mode, a, s);
+}
 
 int pick_L(int L) { return L > 0 ? L : 4; }
 
@@ -239,8 +246,9 @@ int build_gather_plan(const CsrView &A, const std::vector<int32_t> &rows, int L,
                       bool in_place, int mult_col, PlanGpu *out)
 {
     Plan P;
-    const std::string err = build_gather_plan_host(A, rows, L, tile_rows, diag, self, in_place, mult_col, &P);
+    const std::string err = build_gather_plan_host(A, rows, L, tile_rows, diag, self, in_place, mult_col, &P, g_exact);
     if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "plan: " + err);
+    out->exact = g_exact;
     return out->upload(P);
 }
 
@@ -272,7 +280,7 @@ int sweep_once(mmg_level *lv)
     a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
     a.flags8 = lv->flags8.p;
     a.partial = lv->neumann ? lv->partX.p : nullptr;
-    if (g_persistent_sweep && lv->A.n_phases() > 1 && lv->workers > 0) {
+    if (g_persistent_sweep && !lv->A.exact && lv->A.n_phases() > 1 && lv->workers > 0) {
         // one launch: tiles in phase order, started by their dependencies (kernels.hip)
         a.tile_list = lv->A.dev.phase_tiles;
         a.n_list = lv->A.n_tiles;
@@ -287,11 +295,13 @@ int sweep_once(mmg_level *lv)
         for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
             a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
             a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
-            HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+            HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
         }
     }
-    if (lv->neumann)
-        HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+    if (lv->neumann) {
+        if (lv->A.exact) HIPC(launch_mult_update_exact(lv->x.p, lv->b.p, lv->n, lv->flags8.p, lv->omega, g_stream));
+        else HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+    }
     return MMG_OK;
 }
 
@@ -316,7 +326,7 @@ int bound_eval(mmg_level *lv)
     for (int ph = 0; ph < lv->B.n_phases(); ++ph) {
         a.tile_list = lv->B.dev.phase_tiles + lv->B.phase_ptr[ph];
         a.n_list = lv->B.phase_ptr[ph + 1] - lv->B.phase_ptr[ph];
-        HIPC(launch_tile_kernel(MODE_BOUND, a, g_stream));
+        HIPC(run_tiles(lv->B, MODE_BOUND, a, g_stream));
     }
     return MMG_OK;
 }
@@ -352,7 +362,7 @@ int residual_dev(mmg_level *lv, bool norms)
     a.flags8 = lv->flags8.p;
     a.partial = lv->partA.p;
     a.partial2 = lv->neumann ? lv->partX.p : nullptr;
-    HIPC(launch_tile_kernel(MODE_RESID, a, g_stream));
+    HIPC(run_tiles(lv->A, MODE_RESID, a, g_stream));
     if (!lv->B.empty()) {
         TileArgs c{};
         c.p = lv->B.dev;
@@ -361,13 +371,15 @@ int residual_dev(mmg_level *lv, bool norms)
         c.out = lv->r.p;
         c.b = lv->b.p;
         c.partial = lv->partB.p;
-        HIPC(launch_tile_kernel(MODE_RESID, c, g_stream));
+        HIPC(run_tiles(lv->B, MODE_RESID, c, g_stream));
     }
     HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
     if (norms) HIPC(launch_abs_sum(lv->b.p, lv->a_size, lv->partBn.p, g_stream));
     HIPC(launch_resid_finalize(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
                                lv->partBn.p, norms ? lv->n_absb : 0, lv->partX.p, lv->A.n_tiles, lv->x.p, lv->b.p,
                                lv->r.p, lv->n, lv->neumann, lv->scal.p, g_stream));
+    if (lv->A.exact)  // reference's summation order for the multiplier-row residual and both norms
+        HIPC(launch_norms_exact(lv->r.p, lv->b.p, lv->x.p, lv->flags8.p, lv->n, lv->neumann, lv->a_size, lv->scal.p, g_stream));
     if (lv->distributed && g_rccl.comm && g_rccl.nranks > 1)
         NCCLC(g_rccl.AllReduce(lv->scal.p, lv->scal.p, 2, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
     return MMG_OK;
@@ -422,7 +434,7 @@ int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
     a.n_list = R->all.n_tiles;
     a.in = fine->r.p;
     a.out = coarse->b.p;
-    HIPC(launch_tile_kernel(MODE_SET, a, g_stream));
+    HIPC(run_tiles(R->all, MODE_SET, a, g_stream));
     HIPC(launch_scatter_const(coarse->b.p, coarse->dir_idx.p, (int)coarse->dir_idx.n, 0.0, g_stream));
     if (fine->neumann) {
         HIPC(launch_fill(coarse->b.p + (coarse->a_size - 1), 1, 0.0, g_stream));
@@ -448,7 +460,10 @@ int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
                 if (!skip[i]) rows.push_back(i);
             auto pg = std::make_unique<PlanGpu>();
             CsrView A{P->rows, P->cols, P->rowptr.data(), P->col.data(), P->val.data()};
+            const bool saved = g_exact;
+            g_exact = P->all.exact;
             int rc = build_gather_plan(A, rows, P->all.dev.L, 256, false, false, false, -1, pg.get());
+            g_exact = saved;
             if (rc) return rc;
             plan = pg.get();
             P->masked.emplace_back(fine, std::move(pg));
@@ -459,7 +474,7 @@ int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
     a.n_list = plan->n_tiles;
     a.in = coarse->x.p;
     a.out = fine->x.p;
-    HIPC(launch_tile_kernel(MODE_ADD, a, g_stream));
+    HIPC(run_tiles(*plan, MODE_ADD, a, g_stream));
     return MMG_OK;
 }
 
@@ -531,6 +546,7 @@ int mmg_set_option(const char *name, int value)
 {
     if (!name) return fail(MMG_ERR_INVALID, "null option");
     if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value; return MMG_OK; }
+    if (std::strcmp(name, "exact_arithmetic") == 0) { g_exact = value != 0; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -636,8 +652,9 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
     {
         Plan P;
-        const std::string err = build_level_plan(*d, L, &P);
+        const std::string err = build_level_plan(*d, L, &P, g_exact);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
+        lv->A.exact = g_exact;
         if ((rc = lv->A.upload(P))) return rc;
     }
 
@@ -811,7 +828,7 @@ int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
 int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches)
 {
     if (!lv || !kernel_ms || !launches || nsweeps < 1) return fail(MMG_ERR_INVALID, "bad argument");
-    const bool persist = g_persistent_sweep && lv->A.n_phases() > 1 && lv->workers > 0;
+    const bool persist = g_persistent_sweep && !lv->A.exact && lv->A.n_phases() > 1 && lv->workers > 0;
     const int nph = persist ? 1 : lv->A.n_phases();
     const int total = nph * nsweeps;
     std::vector<hipEvent_t> ev((size_t)total * 2);
@@ -847,7 +864,7 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
                 a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
                 a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
                 HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
-                HIPC(launch_tile_kernel(MODE_SOR, a, g_stream));
+                HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
                 HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
                 ++k;
             }
@@ -1076,7 +1093,7 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny)
     a.n_list = m->plan.n_tiles;
     a.in = m->x.p;
     a.out = m->y.p;
-    HIPC(launch_tile_kernel(MODE_SET, a, g_stream));
+    HIPC(run_tiles(m->plan, MODE_SET, a, g_stream));
     HIPC(hipMemcpyAsync(y, m->y.p, sizeof(double) * (size_t)ny, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;

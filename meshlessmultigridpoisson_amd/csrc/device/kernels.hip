@@ -204,23 +204,24 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         }
     };
 
-    // two groups per trip so the register sets alternate without copies
+    // Two groups per trip so the register sets alternate without copies.  The next group's
+    // loads are issued UNCONDITIONALLY (past the end the last group is simply re-read): a
+    // conditional issue would create a control-flow join in front of finish() at which the
+    // compiler has to assume the current group's loads are the youngest in flight and waits
+    // for everything (vmcnt(0)), serialising load latency and compute.
     for (uint32_t g = 0; g < n_groups; g += 2) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
-        const unsigned char *p1 = p + group_bytes_dev(L, nr0, pl0);
-        uint32_t h1 = 0;
-        if (g + 1 < n_groups) {
-            h1 = gh[g + 1];
-            issue_group<L, MAXP>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-        }
+        const bool has1 = g + 1 < n_groups;
+        const unsigned char *p1 = has1 ? p + group_bytes_dev(L, nr0, pl0) : p;
+        const uint32_t h1 = has1 ? gh[g + 1] : h_cur;
+        issue_group<L, MAXP>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
         finish(ra, nr0, pl0);
-        if (g + 1 >= n_groups) break;
+        if (!has1) break;
         const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
-        p = p1 + group_bytes_dev(L, nr1, pl1);
-        if (g + 2 < n_groups) {
-            h_cur = gh[g + 2];
-            issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
-        }
+        const bool has2 = g + 2 < n_groups;
+        p = has2 ? p1 + group_bytes_dev(L, nr1, pl1) : p1;
+        h_cur = has2 ? gh[g + 2] : h1;
+        issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
         finish(rb, nr1, pl1);
     }
 
@@ -369,6 +370,116 @@ hipError_t launch_persist_L(const TileArgs &a, int workers, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// ---- exact-arithmetic kernel ---------------------------------------------------------
+// Validation mode (mmg_set_option("exact_arithmetic", 1)).  One lane per row, entries in the
+// reference's stored (ascending column) order, products and sums rounded separately
+// (__dmul_rn/__dadd_rn: no FMA contraction) and associated exactly like the sequential loops
+// of grid.cpp:126-141 / :89-97 / Eigen's row-major and column-major products.  The iterates
+// are then BITWISE those of the CPU oracle, which proves that the tile/level/phase schedule
+// is the reference's Gauss-Seidel order and that every remaining difference of the fast
+// kernels is association order inside one row.
+template <int MODE>
+__global__ __launch_bounds__(64) void tile_kernel_exact(TileArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *xs = reinterpret_cast<double *>(smem);
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x;
+    if (idx >= a.n_list) return;
+    const int tile = a.tile_list ? a.tile_list[idx] : idx;
+    const TileDesc td = a.p.tiles[tile];
+    const uint32_t n_own = td.n_own, n_halo = td.n_halo;
+    const uint32_t n_slots = n_own + n_halo + 1;
+    for (uint32_t i = lane; i < n_own; i += 64) xs[i] = a.in[td.row0 + i];
+    const int32_t *hl = a.p.halo + td.halo_off;
+    for (uint32_t i = lane; i < n_halo; i += 64) xs[n_own + i] = a.in[hl[i]];
+    if (lane == 0) xs[n_slots - 1] = 0.0;
+    double lam = 0.0;
+    if ((MODE == MODE_SOR || MODE == MODE_RESID) && a.lambda) lam = *a.lambda;
+    __syncthreads();
+    const unsigned char *p = a.p.stream + td.stream_off;
+    const uint32_t *gh = a.p.ghead + td.ghead_off;
+    for (uint32_t g = 0; g < td.n_groups; ++g) {
+        const uint32_t h = gh[g];
+        const int nr = (int)(h & 0xffu), plen = (int)(h >> 8), W = nr;  // L == 1
+        const RowMeta *meta = reinterpret_cast<const RowMeta *>(p);
+        const double *diag = reinterpret_cast<const double *>(p + (size_t)8 * nr);
+        const double *vals = reinterpret_cast<const double *>(p + (size_t)16 * nr);
+        const size_t vbytes = al16((size_t)plen * W * 8);
+        const uint16_t *sl = reinterpret_cast<const uint16_t *>(reinterpret_cast<const unsigned char *>(vals) + vbytes);
+        if (lane < nr) {
+            const RowMeta m = meta[lane];
+            const double d = diag[lane];
+            const int dpos = (int)(m.flags >> 1) - 1;  // -1: no diagonal stored
+            double acc = (MODE == MODE_BOUND) ? a.b[m.gid] : 0.0;
+            for (int q = 0; q <= plen; ++q) {
+                if (MODE == MODE_RESID && q == dpos) acc = __dadd_rn(acc, __dmul_rn(d, xs[m.self]));
+                if (q == plen) break;
+                const double v = vals[(size_t)q * W + lane];
+                const uint16_t s = sl[(((size_t)(q >> 2)) * W + lane) * 4 + (q & 3)];
+                const double pr = __dmul_rn(v, xs[s]);
+                acc = (MODE == MODE_BOUND) ? __dadd_rn(acc, -pr) : __dadd_rn(acc, pr);
+            }
+            if ((MODE == MODE_SOR || MODE == MODE_RESID) && (m.flags & 1)) acc = __dadd_rn(acc, lam);  // last column, coefficient 1
+            if (MODE == MODE_SOR) {
+                double xi = __dadd_rn(a.b[m.gid], -acc);
+                xi = __dmul_rn(xi, a.omega / d);
+                xi = __dadd_rn(xi, __dmul_rn(1.0 - a.omega, xs[m.self]));
+                xs[m.self] = xi;
+            } else if (MODE == MODE_BOUND) {
+                const double xi = acc / d;
+                a.out[m.gid] = xi;
+                if (m.self != kNoSlot) xs[m.self] = xi;
+            } else if (MODE == MODE_RESID) {
+                a.out[m.gid] = __dadd_rn(a.b[m.gid], -acc);
+            } else if (MODE == MODE_SET) {
+                a.out[m.gid] = acc;
+            } else {
+                a.out[m.gid] = __dadd_rn(a.out[m.gid], acc);
+            }
+        }
+        p += group_bytes_dev(1, nr, plen);
+        __syncthreads();
+    }
+    if (MODE == MODE_SOR)
+        for (uint32_t i = lane; i < n_own; i += 64) a.out[td.row0 + i] = xs[i];
+}
+
+// multiplier row in the reference's order: -(x_0 + x_1 + ...) over non-Neumann points, ascending
+__global__ void k_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (flags8[i] < 2) s = __dadd_rn(s, x[i]);
+    double xi = __dadd_rn(b[n], -s);
+    xi = __dmul_rn(xi, omega / 1.0);
+    xi = __dadd_rn(xi, __dmul_rn(1.0 - omega, x[n]));
+    x[n] = xi;
+}
+
+// Eigen lpNorm<1>: sequential; with a multiplier row (neumann) r[n] is first recomputed in
+// the reference's order: b_N - (x_0 + x_1 + ... + x_N)
+__global__ void k_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
+                              int a_size, double *out2)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (neumann) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i)
+            if (flags8[i] < 2) s = __dadd_rn(s, x[i]);
+        s = __dadd_rn(s, x[n]);
+        r[n] = __dadd_rn(b[n], -s);
+    }
+    double sr = 0.0, sb = 0.0;
+    for (int i = 0; i < a_size; ++i) {
+        sr = __dadd_rn(sr, fabs(r[i]));
+        sb = __dadd_rn(sb, fabs(b[i]));
+    }
+    out2[0] = sr;
+    out2[1] = sb;
+}
+
 // ---- small kernels -------------------------------------------------------------
 __global__ void k_fill(double *v, long long n, double c)
 {
@@ -500,6 +611,33 @@ hipError_t sweep_persistent_blocks_per_cu(const PlanDev &p, int *blocks)
     case 64: return occ_L<64>(p, blocks);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_t s)
+{
+    if (a.n_list <= 0) return hipSuccess;
+    if (a.p.L != 1) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)a.n_list), block(64);
+    const size_t lds = a.p.lds_bytes;
+    switch (mode) {
+    case MODE_SOR: hipLaunchKernelGGL(tile_kernel_exact<MODE_SOR>, grid, block, lds, s, a); break;
+    case MODE_BOUND: hipLaunchKernelGGL(tile_kernel_exact<MODE_BOUND>, grid, block, lds, s, a); break;
+    case MODE_RESID: hipLaunchKernelGGL(tile_kernel_exact<MODE_RESID>, grid, block, lds, s, a); break;
+    case MODE_SET: hipLaunchKernelGGL(tile_kernel_exact<MODE_SET>, grid, block, lds, s, a); break;
+    case MODE_ADD: hipLaunchKernelGGL(tile_kernel_exact<MODE_ADD>, grid, block, lds, s, a); break;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mult_update_exact, dim3(1), dim3(64), 0, s, x, b, n, flags8, omega);
+    return hipGetLastError();
+}
+hipError_t launch_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
+                              int a_size, double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_norms_exact, dim3(1), dim3(64), 0, s, r, b, x, flags8, n, neumann, a_size, out2);
+    return hipGetLastError();
 }
 
 hipError_t launch_sweep_persistent(const TileArgs &a, int workers, hipStream_t s)

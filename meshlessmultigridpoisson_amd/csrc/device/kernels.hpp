@@ -49,6 +49,12 @@ struct TileArgs {
 };
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
+// exact-arithmetic variant (plans built with exact = true, L = 1): every row is accumulated by
+// one lane in the reference's stored order with separately rounded multiply and add
+hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_t s);
+hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, hipStream_t s);
+hipError_t launch_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
+                              int a_size, double *out2, hipStream_t s);
 
 // one launch per sweep: `workers` resident wavefronts pull tiles in phase order and wait
 // for their coupled earlier tiles through agent-scope flags

@@ -17,10 +17,10 @@ int widen_L(const CsrView &A, const int32_t *rows, int64_t n_rows, int L)
 }  // namespace
 
 std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows,
-                                   bool diag, bool self, bool in_place, int mult_col, Plan *out)
+                                   bool diag, bool self, bool in_place, int mult_col, Plan *out, bool exact)
 {
     std::string err;
-    L = widen_L(A, rows.data(), (int64_t)rows.size(), L);
+    L = exact ? 1 : widen_L(A, rows.data(), (int64_t)rows.size(), L);
     int tr = std::max(1, tile_rows);
     for (int attempt = 0; attempt < 16; ++attempt) {
         std::vector<int64_t> tp = uniform_tile_ptr((int64_t)rows.size(), tr);
@@ -35,6 +35,7 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
         s.in_place = in_place;
         s.mult_col = mult_col;
         s.L = L;
+        s.exact = exact;
         err = build_plan(s, out);
         if (err.empty()) return err;
         if (err.rfind("tile-too-large", 0) != 0 || tr == 1) break;
@@ -43,7 +44,7 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
     return err;
 }
 
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact)
 {
     const int n = d.n;
     CsrView A{d.a_size, d.a_size, d.rowptr, d.col, d.val};
@@ -66,7 +67,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
         if (d.bcflags[i] == 0) rows.push_back(i);
     if (!rows.empty() && rows.back() >= pt_tile.back()) return "an interior row lies outside every tile";
     std::string err;
-    L = widen_L(A, rows.data(), (int64_t)rows.size(), L);
+    L = exact ? 1 : widen_L(A, rows.data(), (int64_t)rows.size(), L);
     for (int attempt = 0; attempt < 10; ++attempt) {
         const int nt = (int)pt_tile.size() - 1;
         std::vector<int64_t> tp((size_t)nt + 1, 0);
@@ -91,6 +92,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out)
         s.in_place = true;
         s.mult_col = d.neumann_flag ? n : -1;
         s.L = L;
+        s.exact = exact;
         err = build_plan(s, out);
         if (err.empty() || err.rfind("tile-too-large", 0) != 0) return err;
         std::vector<int32_t> split;  // halve every tile and retry

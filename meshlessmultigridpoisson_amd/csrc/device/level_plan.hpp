@@ -13,11 +13,11 @@ namespace mmg {
 // Non-in-place or in-place gather plan over `rows` with automatic tile size
 // (halves tile_rows until every tile fits the LDS slot budget).
 std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> &rows, int L, int tile_rows,
-                                   bool diag, bool self, bool in_place, int mult_col, Plan *out);
+                                   bool diag, bool self, bool in_place, int mult_col, Plan *out, bool exact = false);
 
 // Plan A of a level: interior rows (bcflags == 0) in storage order, own range of
 // a tile == its points.  Tile boundaries come from desc.tile_ptr or tile_size.
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out);
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false);
 
 // Boundary bookkeeping of a level (deduplicated, last writer wins).
 struct BoundaryLists {

@@ -116,7 +116,12 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             const int32_t col = A.col[p];
             const double v = A.val[p];
             if (col == s.mult_col) { flags |= 1; continue; }
-            if (s.extract_diag && col == gid) { diag[k] = v; has_diag = true; continue; }
+            if (s.extract_diag && col == gid) {
+                diag[k] = v;
+                has_diag = true;
+                flags |= (uint16_t)((std::min<size_t>(ent[k].size(), 32766) + 1) << 1);
+                continue;
+            }
             if (v == 0.0) continue;
             ent[k].push_back({slot(col), v});
             if (s.in_place && col != gid) {
@@ -162,7 +167,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             int plen = 0;
             for (int i = 0; i < g; ++i)
                 plen = std::max(plen, (int)((ent[rows[g0 + i]].size() + L - 1) / L));
-            if (plen > 64) { tb.err = "row too long for lanes_per_row (more than 64 entries per lane)"; return; }
+            if (plen > 64 && !s.exact) { tb.err = "row too long for lanes_per_row (more than 64 entries per lane)"; return; }
             const size_t W = (size_t)g * L;
             const size_t plen4 = ((size_t)plen + 3) / 4;
             const size_t base = tb.blob.size();

@@ -53,7 +53,8 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout");
 struct RowMeta {
     uint32_t gid;          // output index of the row
     uint16_t self;         // LDS slot holding in[gid] (kNoSlot: not staged)
-    uint16_t flags;        // bit0: row has the multiplier column (coefficient 1)
+    uint16_t flags;        // bit0: row has the multiplier column (coefficient 1); bits 1..15: 1 + number of
+                           // stored entries that precede the diagonal in the row (exact-arithmetic kernels)
 };
 static_assert(sizeof(RowMeta) == 8, "RowMeta layout");
 
@@ -112,6 +113,7 @@ struct PlanSpec {
     int mult_col = -1;          // column of the dense multiplier (stripped; must be 1.0)
     int L = 4;
     int n_threads = 0;          // 0 = hardware concurrency
+    bool exact = false;         // layout for the exact-arithmetic kernels: L = 1, no entries-per-lane cap
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).
