@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-_PKG = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.environ.get("MMGP_LIBDIR") or os.path.dirname(os.path.abspath(__file__))  # MMGP_LIBDIR: A/B builds
 LIB_PATH = os.path.join(_PKG, "libmmgp_host.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
