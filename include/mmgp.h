@@ -209,6 +209,29 @@ void mmg_spmv_destroy(mmg_spmv *m);
 /* y = A x on host vectors (uploads x, downloads y) */
 int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny);
 
+/* ---- fractional-step grid == FractionalStepGrid (fractionalStepGrid.hpp) -------------------
+ * Velocity predictor, pressure-Poisson source and corrector around the pressure level `p`
+ * (whose values_/source_ are the pressure and the PPE right-hand side).  u, v, u_hat, v_hat
+ * live on the device; D_x, D_y and the velocity Laplacian are row-major CSR over the n points
+ * (derivXMat_, derivYMat_, uvLaplaceMat_); nx, ny are normalVecs_; bpts every boundary point. */
+typedef struct mmg_fracstep mmg_fracstep;
+int mmg_fracstep_create(mmg_fracstep **out, mmg_level *p, int n, const int *dx_rowptr, const int *dx_col,
+                        const double *dx_val, const int *dy_rowptr, const int *dy_col, const double *dy_val,
+                        const int *lap_rowptr, const int *lap_col, const double *lap_val, const double *nx,
+                        const double *ny, const int *bpts, int nbpts);
+void mmg_fracstep_destroy(mmg_fracstep *fs);
+/* which: 0 u, 1 v, 2 u_hat, 3 v_hat */
+int mmg_fracstep_set(mmg_fracstep *fs, int which, const double *w, int count);
+int mmg_fracstep_get(mmg_fracstep *fs, int which, double *w, int count);
+/* calc_u_hat + calc_v_hat  fractionalStepGrid.cpp:101-124 */
+int mmg_fracstep_calc_hat(mmg_fracstep *fs, double dt, double mu, double rho);
+/* set_ppe_source  :125-145 (writes the pressure level's source_[0:n)) */
+int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho);
+/* correct_u + correct_v  :146-151 (reads the pressure level's values_[0:n)) */
+int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho);
+/* fs_residual  :152-154 */
+int mmg_fracstep_residual(mmg_fracstep *fs, double *value);
+
 #ifdef __cplusplus
 }
 #endif

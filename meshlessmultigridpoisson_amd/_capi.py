@@ -46,7 +46,9 @@ SYMBOLS = [
     "mmg_level_residual_ratio", "mmg_level_boundary_op", "mmg_level_modify_coeff_neumann", "mmg_level_zero_x",
     "mmg_level_time_sweeps", "mmg_level_time_residual", "mmg_level_time_phases", "mmg_transfer_create", "mmg_transfer_destroy",
     "mmg_restrict", "mmg_prolong_add", "mmg_hierarchy_create", "mmg_hierarchy_destroy", "mmg_vcycle",
-    "mmg_hierarchy_residual", "mmg_vcycles", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply",
+    "mmg_hierarchy_residual", "mmg_vcycles", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply", "mmg_fracstep_create", "mmg_fracstep_destroy",
+    "mmg_fracstep_set", "mmg_fracstep_get", "mmg_fracstep_calc_hat", "mmg_fracstep_set_ppe_source",
+    "mmg_fracstep_correct", "mmg_fracstep_residual",
 ]
 
 _lib = None
@@ -97,6 +99,16 @@ def lib():
         L.mmg_spmv_destroy.argtypes = [vp]
         L.mmg_spmv_destroy.restype = None
         L.mmg_spmv_apply.argtypes = [vp, _dp, C.c_int, _dp, C.c_int]
+        L.mmg_fracstep_create.argtypes = [C.POINTER(vp), vp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, _dp, _dp,
+                                          _ip, C.c_int]
+        L.mmg_fracstep_destroy.argtypes = [vp]
+        L.mmg_fracstep_destroy.restype = None
+        L.mmg_fracstep_set.argtypes = [vp, C.c_int, _dp, C.c_int]
+        L.mmg_fracstep_get.argtypes = [vp, C.c_int, _dp, C.c_int]
+        L.mmg_fracstep_calc_hat.argtypes = [vp, C.c_double, C.c_double, C.c_double]
+        L.mmg_fracstep_set_ppe_source.argtypes = [vp, C.c_double, C.c_double]
+        L.mmg_fracstep_correct.argtypes = [vp, C.c_double, C.c_double]
+        L.mmg_fracstep_residual.argtypes = [vp, _dp]
         L.mmg_set_stream.argtypes = [vp]
         L.mmg_set_device.argtypes = [C.c_int]
         L.mmg_device_count.argtypes = [_ip]
@@ -375,3 +387,47 @@ class Spmv:
         y = np.zeros(self.rows)
         check(lib().mmg_spmv_apply(self.h, _pd(x), len(x), _pd(y), len(y)))
         return y
+
+
+class FracStep:
+    """Device-side FractionalStepGrid ops around a pressure Level (fractionalStepGrid.cpp:101-154)."""
+    U, V, U_HAT, V_HAT = 0, 1, 2, 3
+
+    def __init__(self, level, dx, dy, lap, nx, ny, bpts):
+        self.level, self.n = level, level.n
+        arrs = []
+        for (rp, col, val) in (dx, dy, lap):
+            arrs += [_i(rp), _i(col), _d(val)]
+        nx, ny, bpts = _d(nx), _d(ny), _i(bpts)
+        self.h = C.c_void_p()
+        check(lib().mmg_fracstep_create(C.byref(self.h), level.h, self.n, _pi(arrs[0]), _pi(arrs[1]), _pd(arrs[2]),
+                                        _pi(arrs[3]), _pi(arrs[4]), _pd(arrs[5]), _pi(arrs[6]), _pi(arrs[7]),
+                                        _pd(arrs[8]), _pd(nx), _pd(ny), _pi(bpts), len(bpts)))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mmg_fracstep_destroy(self.h)
+            self.h = None
+
+    def set(self, which, w):
+        w = _d(w)
+        check(lib().mmg_fracstep_set(self.h, which, _pd(w), len(w)))
+
+    def get(self, which):
+        w = np.zeros(self.n)
+        check(lib().mmg_fracstep_get(self.h, which, _pd(w), len(w)))
+        return w
+
+    def calc_hat(self, dt, mu, rho):
+        check(lib().mmg_fracstep_calc_hat(self.h, dt, mu, rho))
+
+    def set_ppe_source(self, dt, rho):
+        check(lib().mmg_fracstep_set_ppe_source(self.h, dt, rho))
+
+    def correct(self, dt, rho):
+        check(lib().mmg_fracstep_correct(self.h, dt, rho))
+
+    def residual(self):
+        v = C.c_double(0)
+        check(lib().mmg_fracstep_residual(self.h, C.byref(v)))
+        return v.value

@@ -76,6 +76,17 @@ def lib():
         L.mmgh_order_from_txt.argtypes = [C.c_char_p, C.c_int]
         L.mmgh_write_msh.argtypes = [C.c_char_p, _dp, C.c_int]
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
+        L.mmgh_fs_create_square.restype = vp
+        L.mmgh_fs_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.mmgh_fs_op_nnz.argtypes = [vp, C.c_int]
+        L.mmgh_fs_op_get.argtypes = [vp, C.c_int, _ip, _ip, _dp]
+        L.mmgh_fs_get_normals.argtypes = [vp, _dp, _dp]
+        L.mmgh_fs_get_vec.argtypes = [vp, C.c_int, _dp]
+        L.mmgh_fs_set_vec.argtypes = [vp, C.c_int, _dp]
+        for f in ("mmgh_fs_prescribe_soln", "mmgh_fs_set_uv_bound", "mmgh_fs_calc_hat", "mmgh_fs_set_ppe_source",
+                  "mmgh_fs_push_inhomog", "mmgh_fs_correct"):
+            getattr(L, f).argtypes = [vp]
+        L.mmgh_fs_residual.argtypes = [vp, _dp]
         L.mmgh_grid_partition_slabs.argtypes = [vp, C.c_int, _ip]
         L.mmgh_grid_extract_subdomain.restype = vp
         L.mmgh_grid_extract_subdomain.argtypes = [vp, _ip, C.c_int]
@@ -273,6 +284,75 @@ class Grid:
         out = np.zeros(k, dtype=np.int32)
         n = lib().mmgh_grid_knn(self.h, pid, k, out.ctypes.data_as(_ip))
         return out[:n]
+
+
+class FracStepGrid(Grid):
+    """Handle on a C++ `FractionalStepGrid` (csrc/host/fractionalStepGrid.hpp), built by the
+    call sequence of genFractionalStepGrid (FractionalStepSim.cpp:3-49)."""
+
+    @classmethod
+    def create(cls, points, polydeg=3, dt=2e-4, mu=0.025, rho=1.0, ordering=ORDER_MC, tile_points=0, coarse=False):
+        pts = _d(points).reshape(-1, 3)
+        h = lib().mmgh_fs_create_square(len(pts), pts.ctypes.data_as(_dp), polydeg, dt, mu, rho, ordering, tile_points,
+                                        int(coarse))
+        if not h:
+            raise HostError(_err())
+        g = cls(h)
+        g._own = True
+        g.dt, g.mu, g.rho = dt, mu, rho
+        return g
+
+    def op(self, which):
+        n = self.sizes()["n"]
+        nnz = lib().mmgh_fs_op_nnz(self.h, which)
+        rp, col, val = np.zeros(n + 1, dtype=np.int32), np.zeros(nnz, dtype=np.int32), np.zeros(nnz)
+        lib().mmgh_fs_op_get(self.h, which, rp.ctypes.data_as(_ip), col.ctypes.data_as(_ip), val.ctypes.data_as(_dp))
+        return rp, col, val
+
+    def normals(self):
+        n = self.sizes()["n"]
+        nx, ny = np.zeros(n), np.zeros(n)
+        lib().mmgh_fs_get_normals(self.h, nx.ctypes.data_as(_dp), ny.ctypes.data_as(_dp))
+        return nx, ny
+
+    def vec(self, which):
+        w = np.zeros(self.sizes()["n"])
+        _chk(lib().mmgh_fs_get_vec(self.h, which, w.ctypes.data_as(_dp)))
+        return w
+
+    def set_vec(self, which, w):
+        w = _d(w)
+        lib().mmgh_fs_set_vec(self.h, which, w.ctypes.data_as(_dp))
+
+    def prescribe_soln(self):
+        lib().mmgh_fs_prescribe_soln(self.h)
+
+    def set_uv_bound(self):
+        lib().mmgh_fs_set_uv_bound(self.h)
+
+    def calc_hat(self):
+        _chk(lib().mmgh_fs_calc_hat(self.h))
+
+    def set_ppe_source(self):
+        _chk(lib().mmgh_fs_set_ppe_source(self.h))
+
+    def push_inhomog_to_rhs(self):
+        _chk(lib().mmgh_fs_push_inhomog(self.h))
+
+    def correct(self):
+        _chk(lib().mmgh_fs_correct(self.h))
+
+    def fs_residual(self):
+        v = C.c_double(0)
+        _chk(lib().mmgh_fs_residual(self.h, C.byref(v)))
+        return v.value
+
+    def oracle(self):
+        """Oracle objects over the operators this grid built (tests only)."""
+        from oracle import oracle_c as oc
+        nx, ny = self.normals()
+        _bt, _bp, bpts, _bv = self.boundaries()
+        return oc.FracStep(self.sizes()["n"], self.op(0), self.op(1), self.op(2), nx, ny, bpts)
 
 
 class Multigrid:

@@ -234,6 +234,16 @@ struct mmg_hierarchy {
     int frac_step = 0;
 };
 
+struct mmg_fracstep {
+    mmg_level *p = nullptr;
+    int n = 0;
+    PlanGpu dx, dy, lap;
+    DevBuf<double> w[4];       // u, v, u_hat, v_hat
+    DevBuf<double> t1, t2, t3;  // operator outputs
+    DevBuf<double> nx, ny, partial, scal;
+    DevBuf<int32_t> bpts;
+};
+
 struct mmg_spmv {
     int rows = 0, cols = 0;
     PlanGpu plan;
@@ -1096,6 +1106,125 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny)
     HIPC(run_tiles(m->plan, MODE_SET, a, g_stream));
     HIPC(hipMemcpyAsync(y, m->y.p, sizeof(double) * (size_t)ny, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+// ---- fractional-step grid --------------------------------------------------------------
+int mmg_fracstep_create(mmg_fracstep **out, mmg_level *p, int n, const int *dx_rowptr, const int *dx_col,
+                        const double *dx_val, const int *dy_rowptr, const int *dy_col, const double *dy_val,
+                        const int *lap_rowptr, const int *lap_col, const double *lap_val, const double *nx,
+                        const double *ny, const int *bpts, int nbpts)
+{
+    if (!out || !p || n < 1 || n != p->n || !dx_rowptr || !dy_rowptr || !lap_rowptr || !nx || !ny || nbpts < 0)
+        return fail(MMG_ERR_INVALID, "fracstep_create: bad argument");
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    auto fs = std::make_unique<mmg_fracstep>();
+    fs->p = p;
+    fs->n = n;
+    std::vector<int32_t> rows((size_t)n);
+    for (int i = 0; i < n; ++i) rows[i] = i;
+    const int L = p->A.dev.L;
+    CsrView A1{n, n, dx_rowptr, dx_col, dx_val}, A2{n, n, dy_rowptr, dy_col, dy_val}, A3{n, n, lap_rowptr, lap_col, lap_val};
+    if ((rc = build_gather_plan(A1, rows, L, 256, false, false, false, -1, &fs->dx))) return rc;
+    if ((rc = build_gather_plan(A2, rows, L, 256, false, false, false, -1, &fs->dy))) return rc;
+    if ((rc = build_gather_plan(A3, rows, L, 256, false, false, false, -1, &fs->lap))) return rc;
+    for (auto &b : fs->w) {
+        HIPC(b.alloc((size_t)n));
+        HIPC(hipMemset(b.p, 0, sizeof(double) * (size_t)n));
+    }
+    HIPC(fs->t1.alloc((size_t)n));
+    HIPC(fs->t2.alloc((size_t)n));
+    HIPC(fs->t3.alloc((size_t)n));
+    HIPC(hipMemset(fs->t1.p, 0, sizeof(double) * (size_t)n));
+    HIPC(hipMemset(fs->t2.p, 0, sizeof(double) * (size_t)n));
+    HIPC(hipMemset(fs->t3.p, 0, sizeof(double) * (size_t)n));
+    HIPC(fs->nx.upload(nx, (size_t)n));
+    HIPC(fs->ny.upload(ny, (size_t)n));
+    HIPC(fs->bpts.upload(bpts, (size_t)nbpts));
+    HIPC(fs->partial.alloc((size_t)std::max(1, abs_sum_blocks(n))));
+    HIPC(fs->scal.alloc(1));
+    *out = fs.release();
+    return MMG_OK;
+}
+void mmg_fracstep_destroy(mmg_fracstep *fs) { delete fs; }
+
+int mmg_fracstep_set(mmg_fracstep *fs, int which, const double *w, int count)
+{
+    if (!fs || !w || which < 0 || which > 3 || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_set: bad argument");
+    HIPC(hipMemcpyAsync(fs->w[which].p, w, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+int mmg_fracstep_get(mmg_fracstep *fs, int which, double *w, int count)
+{
+    if (!fs || !w || which < 0 || which > 3 || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_get: bad argument");
+    HIPC(hipMemcpyAsync(w, fs->w[which].p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+namespace {
+int fs_apply(const PlanGpu &pl, const double *in, double *outv)
+{
+    TileArgs a{};
+    a.p = pl.dev;
+    a.n_list = pl.n_tiles;
+    a.in = in;
+    a.out = outv;
+    HIPC(run_tiles(pl, MODE_SET, a, g_stream));
+    return MMG_OK;
+}
+}  // namespace
+
+int mmg_fracstep_calc_hat(mmg_fracstep *fs, double dt, double mu, double rho)
+{
+    if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
+    int rc;
+    const double *u = fs->w[0].p, *v = fs->w[1].p;
+    for (int c = 0; c < 2; ++c) {
+        const double *w = fs->w[c].p;
+        if ((rc = fs_apply(fs->dx, w, fs->t1.p))) return rc;
+        if ((rc = fs_apply(fs->dy, w, fs->t2.p))) return rc;
+        if ((rc = fs_apply(fs->lap, w, fs->t3.p))) return rc;
+        HIPC(launch_fs_hat(fs->w[2 + c].p, w, u, v, fs->t1.p, fs->t2.p, fs->t3.p, dt, mu / rho, fs->n, g_stream));
+    }
+    return MMG_OK;
+}
+
+int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho)
+{
+    if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
+    int rc;
+    if ((rc = fs_apply(fs->dx, fs->w[2].p, fs->t1.p))) return rc;
+    if ((rc = fs_apply(fs->dy, fs->w[3].p, fs->t2.p))) return rc;
+    HIPC(launch_fs_ppe_interior(fs->p->b.p, fs->t1.p, fs->t2.p, rho / dt, fs->n, g_stream));
+    HIPC(launch_fs_ppe_boundary(fs->p->b.p, fs->bpts.p, (int)fs->bpts.n, fs->w[0].p, fs->w[1].p, fs->w[2].p, fs->w[3].p,
+                                fs->nx.p, fs->ny.p, rho / dt, g_stream));
+    return MMG_OK;
+}
+
+int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho)
+{
+    if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
+    int rc;
+    if ((rc = fs_apply(fs->dx, fs->p->x.p, fs->t1.p))) return rc;
+    HIPC(launch_fs_correct(fs->w[0].p, fs->w[2].p, fs->t1.p, dt / rho, fs->n, g_stream));
+    if ((rc = fs_apply(fs->dy, fs->p->x.p, fs->t2.p))) return rc;
+    HIPC(launch_fs_correct(fs->w[1].p, fs->w[3].p, fs->t2.p, dt / rho, fs->n, g_stream));
+    return MMG_OK;
+}
+
+int mmg_fracstep_residual(mmg_fracstep *fs, double *value)
+{
+    if (!fs || !value) return fail(MMG_ERR_INVALID, "null argument");
+    HIPC(launch_abs_diff_sum(fs->w[0].p, fs->w[2].p, fs->n, fs->partial.p, g_stream));
+    HIPC(launch_sum_partials(fs->partial.p, abs_sum_blocks(fs->n), fs->scal.p, g_stream));
+    double h = 0;
+    HIPC(hipMemcpyAsync(&h, fs->scal.p, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    *value = h / fs->n;
     return MMG_OK;
 }
 

@@ -559,6 +559,9 @@ __global__ __launch_bounds__(256) void k_mult_update(double *x, const double *b,
 
 constexpr int kAbsBlock = 256;
 constexpr int kAbsPerBlock = 256 * 16;
+}  // namespace
+int abs_sum_blocks(long long n) { return (int)((n + kAbsPerBlock - 1) / kAbsPerBlock); }
+namespace {
 
 __global__ __launch_bounds__(256) void k_abs_sum(const double *v, long long n, double *partial)
 {
@@ -600,7 +603,94 @@ __global__ __launch_bounds__(256) void k_resid_finalize(const double *pa, int na
     }
 }
 
+// ---- fractional-step pointwise kernels ------------------------------------------------
+__global__ void k_fs_hat(double *wh, const double *w, const double *u, const double *v, const double *wx, const double *wy,
+                         const double *lap, double dt, double mor, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wh[i] = w[i] + dt * (-(u[i] * wx[i] + v[i] * wy[i]) + mor * lap[i]);
+}
+__global__ void k_fs_ppe_interior(double *b, const double *a, const double *c, double rod, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = rod * (a[i] + c[i]);
+}
+__global__ void k_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const double *u, const double *v, const double *uh,
+                                  const double *vh, const double *nx, const double *ny, double rod)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const int p = bpts[k];
+    const double dpdx = -rod * (u[p] - uh[p]);
+    const double dpdy = -rod * (v[p] - vh[p]);
+    b[p] = nx[p] * dpdx + ny[p] * dpdy;
+}
+__global__ void k_fs_correct(double *w, const double *wh, const double *g, double dor, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = wh[i] - dor * g[i];
+}
+__global__ __launch_bounds__(256) void k_abs_diff_sum(const double *a, const double *b, long long n, double *partial)
+{
+    __shared__ double sh[256];
+    const long long base = (long long)blockIdx.x * kAbsPerBlock;
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) {
+        const long long i = base + (long long)k * 256 + threadIdx.x;
+        if (i < n) s += fabs(a[i] - b[i]);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_sum_partials(const double *partial, int n, double *out)
+{
+    __shared__ double sh[256];
+    const double s = block_sum_256(partial, n, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
 }  // namespace
+
+hipError_t launch_fs_hat(double *w_hat, const double *w, const double *u, const double *v, const double *wx,
+                         const double *wy, const double *lap, double dt, double mor, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fs_hat, dim3((n + 255) / 256), dim3(256), 0, s, w_hat, w, u, v, wx, wy, lap, dt, mor, n);
+    return hipGetLastError();
+}
+hipError_t launch_fs_ppe_interior(double *b, const double *a, const double *c, double rod, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fs_ppe_interior, dim3((n + 255) / 256), dim3(256), 0, s, b, a, c, rod, n);
+    return hipGetLastError();
+}
+hipError_t launch_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const double *u, const double *v,
+                                  const double *uh, const double *vh, const double *nx, const double *ny, double rod,
+                                  hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fs_ppe_boundary, dim3((nb + 255) / 256), dim3(256), 0, s, b, bpts, nb, u, v, uh, vh, nx, ny, rod);
+    return hipGetLastError();
+}
+hipError_t launch_fs_correct(double *w, const double *w_hat, const double *g, double dor, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fs_correct, dim3((n + 255) / 256), dim3(256), 0, s, w, w_hat, g, dor, n);
+    return hipGetLastError();
+}
+hipError_t launch_abs_diff_sum(const double *a, const double *b, long long n, double *partial, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_abs_diff_sum, dim3(abs_sum_blocks(n)), dim3(kAbsBlock), 0, s, a, b, n, partial);
+    return hipGetLastError();
+}
+hipError_t launch_sum_partials(const double *partial, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, partial, n, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s)
 {
@@ -714,7 +804,7 @@ hipError_t launch_mult_update(double *x, const double *b, int n, const double *p
     hipLaunchKernelGGL(k_mult_update, dim3(1), dim3(256), 0, s, x, b, n, partial, n_partial, omega);
     return hipGetLastError();
 }
-int abs_sum_blocks(long long n) { return (int)((n + kAbsPerBlock - 1) / kAbsPerBlock); }
+
 hipError_t launch_abs_sum(const double *v, long long n, double *partial, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;

@@ -77,4 +77,21 @@ hipError_t launch_resid_finalize(const double *pa, int na, const double *pb, int
                                  const double *px, int npx, const double *x, const double *b, double *r, int n,
                                  int neumann, double *out2, hipStream_t s);
 
+// ---- fractional-step pointwise kernels (fractionalStepGrid.cpp:101-154) -------------------
+// w_hat = w + dt * (-(u*wx + v*wy) + mu/rho * lap)
+hipError_t launch_fs_hat(double *w_hat, const double *w, const double *u, const double *v, const double *wx,
+                         const double *wy, const double *lap, double dt, double mu_over_rho, int n, hipStream_t s);
+// b = rho_over_dt * (a + c)
+hipError_t launch_fs_ppe_interior(double *b, const double *a, const double *c, double rho_over_dt, int n, hipStream_t s);
+// b[p] = nx[p]*(-rho/dt*(u-u_hat)[p]) + ny[p]*(-rho/dt*(v-v_hat)[p]) for boundary points p
+hipError_t launch_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const double *u, const double *v,
+                                  const double *uh, const double *vh, const double *nx, const double *ny,
+                                  double rho_over_dt, hipStream_t s);
+// w = w_hat - dt_over_rho * g
+hipError_t launch_fs_correct(double *w, const double *w_hat, const double *g, double dt_over_rho, int n, hipStream_t s);
+// partial[block] = sum |a - b|
+hipError_t launch_abs_diff_sum(const double *a, const double *b, long long n, double *partial, hipStream_t s);
+// out[0] = sum(partial)
+hipError_t launch_sum_partials(const double *partial, int n, double *out, hipStream_t s);
+
 }  // namespace mmg

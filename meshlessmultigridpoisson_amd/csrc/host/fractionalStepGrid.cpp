@@ -1,0 +1,210 @@
+// fractionalStepGrid.cpp -- see fractionalStepGrid.hpp.
+#include "fractionalStepGrid.hpp"
+
+#include <atomic>
+#include <cmath>
+#include <stdexcept>
+#include <thread>
+
+#include "../../../include/mmgp.h"
+
+#define MMG_PI 3.141592653589793238462643383279502884  // EIGEN_PI
+
+using mmgh::Triplet;
+
+namespace {
+void dev_check(int rc, const char *what)
+{
+    if (rc != MMG_OK) throw std::runtime_error(std::string(what) + ": " + mmg_last_error());
+}
+}  // namespace
+
+// fractionalStepGrid.cpp:2-17
+FractionalStepGrid::FractionalStepGrid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties,
+                                       VectorXd source)
+    : Grid(std::move(points), std::move(boundaries), properties, std::move(source))
+{
+    const size_t n = (size_t)laplaceMatSize_;
+    u = new VectorXd(n);
+    u_old = new VectorXd(n);
+    v = new VectorXd(n);
+    v_old = new VectorXd(n);
+    u_hat = new VectorXd(n);
+    v_hat = new VectorXd(n);
+}
+
+FractionalStepGrid::~FractionalStepGrid()
+{
+    if (fs_) {
+        for (VectorXd *w : {u, v, u_hat, v_hat}) w->detach();
+        mmg_fracstep_destroy(fs_);
+    }
+    delete u_hat;
+    delete v_hat;
+    delete u;
+    delete v;
+    delete u_old;
+    delete v_old;
+    delete derivXMat_;
+    delete derivYMat_;
+    delete uvLaplaceMat_;
+}
+
+// fractionalStepGrid.cpp:26-40 -- Kovasznay flow, Re = rho/mu
+void FractionalStepGrid::prescribe_soln()
+{
+    const double re = rho / mu;
+    lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * MMG_PI * MMG_PI);
+    for (int i = 0; i < laplaceMatSize_; ++i) {
+        const double x = std::get<0>(points_[(size_t)i]), y = std::get<1>(points_[(size_t)i]);
+        const double uu = 1 - std::exp(lambda * x) * std::cos(2 * MMG_PI * y);
+        const double vv = lambda / (2 * MMG_PI) * std::exp(lambda * x) * std::sin(2 * MMG_PI * y);
+        u->coeffRef(i) = uu;
+        v->coeffRef(i) = vv;
+        u_old->coeffRef(i) = uu;
+        v_old->coeffRef(i) = vv;
+        values_->coeffRef(i) = 0.5 * std::exp(2 * lambda * x);
+    }
+    values_->coeffRef(laplaceMatSize_) = 0;
+}
+
+// fractionalStepGrid.cpp:41-59
+void FractionalStepGrid::set_uv_bound()
+{
+    const double re = rho / mu;
+    lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * MMG_PI * MMG_PI);
+    if (flowType.compare("kovasznay") != 0) return;
+    for (const Boundary &b : boundaries_)
+        for (int p : b.bcPoints) {
+            const double x = std::get<0>(points_[(size_t)p]), y = std::get<1>(points_[(size_t)p]);
+            const double uu = 1 - std::exp(lambda * x) * std::cos(2 * MMG_PI * y);
+            const double vv = lambda / (2 * MMG_PI) * std::exp(lambda * x) * std::sin(2 * MMG_PI * y);
+            u->coeffRef(p) = uu;
+            v->coeffRef(p) = vv;
+            u_old->coeffRef(p) = uu;
+            v_old->coeffRef(p) = vv;
+        }
+}
+
+// fractionalStepGrid.cpp:60-100: one stencil row for EVERY point (which: 0 d/dx, 1 d/dy, 2 Laplacian)
+Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
+{
+    const int n = laplaceMatSize_;
+    ensure_knn();
+    std::vector<std::vector<double>> W((size_t)n);
+    std::vector<vector<int>> NB((size_t)n);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(8);
+            if (i >= n) break;
+            for (int k = i; k < std::min(n, i + 8); ++k) {
+                auto w = which == 0 ? derivx_weights(k) : (which == 1 ? derivy_weights(k) : laplaceWeights(k));
+                W[(size_t)k] = w.first.host();
+                NB[(size_t)k] = std::move(w.second);
+            }
+        }
+    };
+    const int nth = std::max(1, std::min(threads(), n / 64 + 1));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) th.emplace_back(work);
+    for (auto &x : th) x.join();
+    vector<Triplet> trip;
+    for (int i = 0; i < n; ++i)
+        for (size_t j = 0; j < NB[(size_t)i].size(); ++j) trip.emplace_back(i, NB[(size_t)i][j], W[(size_t)i][j]);
+    SparseRowMajor *m = new SparseRowMajor(n, n, true);
+    m->setFromTriplets(trip.begin(), trip.end());
+    return m;
+}
+
+void FractionalStepGrid::build_derivX_mat() { delete derivXMat_; derivXMat_ = build_op(0); }
+void FractionalStepGrid::build_derivY_mat() { delete derivYMat_; derivYMat_ = build_op(1); }
+void FractionalStepGrid::build_uv_laplace_mat() { delete uvLaplaceMat_; uvLaplaceMat_ = build_op(2); }
+
+void FractionalStepGrid::fs_device()
+{
+    if (fs_) return;
+    if (!derivXMat_ || !derivYMat_ || !uvLaplaceMat_) throw std::runtime_error("FractionalStepGrid: build_deriv*/uv_laplace matrices first");
+    sync_to_device();
+    const int n = laplaceMatSize_;
+    std::vector<double> nx((size_t)n), ny((size_t)n);
+    for (int i = 0; i < n; ++i) { nx[(size_t)i] = std::get<0>(normalVecs_[(size_t)i]); ny[(size_t)i] = std::get<1>(normalVecs_[(size_t)i]); }
+    std::vector<int> bpts;
+    for (const Boundary &b : boundaries_) bpts.insert(bpts.end(), b.bcPoints.begin(), b.bcPoints.end());
+    dev_check(mmg_fracstep_create(&fs_, device(), n, derivXMat_->outerIndexPtr(), derivXMat_->innerIndexPtr(),
+                                  derivXMat_->valuePtr(), derivYMat_->outerIndexPtr(), derivYMat_->innerIndexPtr(),
+                                  derivYMat_->valuePtr(), uvLaplaceMat_->outerIndexPtr(), uvLaplaceMat_->innerIndexPtr(),
+                                  uvLaplaceMat_->valuePtr(), nx.data(), ny.data(), bpts.data(), (int)bpts.size()),
+              "mmg_fracstep_create");
+    attach_fs_mirrors();
+}
+
+void FractionalStepGrid::attach_fs_mirrors()
+{
+    mmg_fracstep *h = fs_;
+    VectorXd *vecs[4] = {u, v, u_hat, v_hat};
+    for (int k = 0; k < 4; ++k) {
+        vecs[k]->attach([h, k](double *dst, size_t cnt) { dev_check(mmg_fracstep_get(h, k, dst, (int)cnt), "mmg_fracstep_get"); });
+        vecs[k]->host_mut();  // nothing uploaded yet
+    }
+}
+
+void FractionalStepGrid::push_uv()
+{
+    fs_device();
+    VectorXd *vecs[4] = {u, v, u_hat, v_hat};
+    for (int k = 0; k < 4; ++k)
+        if (vecs[k]->host_newer()) {
+            dev_check(mmg_fracstep_set(fs_, k, vecs[k]->data(), (int)vecs[k]->rows()), "mmg_fracstep_set");
+            vecs[k]->mark_uploaded();
+        }
+}
+
+// The reference computes u_hat and v_hat by two calls that both read u and v
+// (fractionalStepGrid.cpp:101-124); the device entry produces both, so the second call is free.
+void FractionalStepGrid::calc_u_hat()
+{
+    push_uv();
+    dev_check(mmg_fracstep_calc_hat(fs_, dt, mu, rho), "mmg_fracstep_calc_hat");
+    u_hat->mark_device_newer();
+    v_hat->mark_device_newer();
+    hat_done_ = true;
+}
+void FractionalStepGrid::calc_v_hat()
+{
+    if (hat_done_ && !u->host_newer() && !v->host_newer()) { hat_done_ = false; return; }
+    calc_u_hat();
+    hat_done_ = false;
+}
+
+void FractionalStepGrid::set_ppe_source()
+{
+    push_uv();
+    sync_to_device();
+    dev_check(mmg_fracstep_set_ppe_source(fs_, dt, rho), "mmg_fracstep_set_ppe_source");
+    mark_source_on_device();
+}
+
+void FractionalStepGrid::correct_u()
+{
+    push_uv();
+    sync_to_device();
+    dev_check(mmg_fracstep_correct(fs_, dt, rho), "mmg_fracstep_correct");
+    u->mark_device_newer();
+    v->mark_device_newer();
+    hat_done_ = true;  // reuse the flag: correct_v() right after is already done
+}
+void FractionalStepGrid::correct_v()
+{
+    if (hat_done_) { hat_done_ = false; return; }
+    correct_u();
+    hat_done_ = false;
+}
+
+double FractionalStepGrid::fs_residual()
+{
+    push_uv();
+    double r = 0;
+    dev_check(mmg_fracstep_residual(fs_, &r), "mmg_fracstep_residual");
+    return r;
+}

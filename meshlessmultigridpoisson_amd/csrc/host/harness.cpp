@@ -14,6 +14,7 @@
 
 #include "../../../include/mmgp.h"
 #include "fileReadingFunctions.h"
+#include "fractionalStepGrid.hpp"
 #include "multigrid.h"
 
 #define PI_REF 3.141592653589793238462643383279  // testing_functions.hpp:9
@@ -313,6 +314,80 @@ int mmgh_grid_sor_wrong_args(void *gp)  // error behaviour check: foreign vector
 {
     return guard([&]() { Grid *g = static_cast<Grid *>(gp); mmgh::Vec other(g->values_->rows()); g->sor(g->laplaceMat_, &other, &g->source_); });
 }
+
+// ---- FractionalStepGrid (FractionalStepSim.cpp:3-49 genFractionalStepGrid) ----------------------
+void *mmgh_fs_create_square(int n, const double *xyz, int polydeg, double dt, double mu, double rho, int ordering,
+                            int tile_points, int coarse)
+{
+    FractionalStepGrid *g = nullptr;
+    const int rc = guard([&]() {
+        std::vector<Point> pts = to_points(xyz, n);
+        GridProperties props = make_props(polydeg, 2, 1.4, 5);
+        const double re = rho / mu;
+        const double lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * PI_REF * PI_REF);
+        Boundary b;
+        b.type = 2;
+        for (int i = 0; i < n; ++i)
+            if (on_box_boundary(pts[(size_t)i], 2)) { b.bcPoints.push_back(i); b.values.push_back(0.5 * std::exp(2 * lambda * std::get<0>(pts[(size_t)i]))); }
+        g = new FractionalStepGrid(pts, std::vector<Boundary>(1, b), props, mmgh::Vec((size_t)n + 1));
+        g->mu = mu;
+        g->rho = rho;
+        g->dt = dt;
+        g->ppe_conv_res = 1e-10;
+        g->implicitFlag_ = true;
+        g->flowType = "kovasznay";
+        g->setBCFlag(0, "neumann", b.values);
+        g->build_normal_vecs("", "square");
+        order_points(g, ordering, tile_points);
+        g->build_deriv_normal_bound();
+        g->build_laplacian();
+        g->modify_coeff_neumann(coarse ? "coarse" : "fine");
+        g->build_derivX_mat();
+        g->build_derivY_mat();
+        g->build_uv_laplace_mat();
+        g->push_inhomog_to_rhs();
+    });
+    if (rc) { delete g; return nullptr; }
+    return g;
+}
+// which: 0 D_x, 1 D_y, 2 velocity Laplacian
+int mmgh_fs_op_nnz(void *gp, int which)
+{
+    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
+    mmgh::Sparse *m = which == 0 ? g->derivXMat_ : (which == 1 ? g->derivYMat_ : g->uvLaplaceMat_);
+    return m->nonZeros();
+}
+void mmgh_fs_op_get(void *gp, int which, int *rowptr, int *col, double *val)
+{
+    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
+    mmgh::Sparse *m = which == 0 ? g->derivXMat_ : (which == 1 ? g->derivYMat_ : g->uvLaplaceMat_);
+    std::memcpy(rowptr, m->outerIndexPtr(), sizeof(int) * ((size_t)m->rows() + 1));
+    std::memcpy(col, m->innerIndexPtr(), sizeof(int) * (size_t)m->nonZeros());
+    std::memcpy(val, m->valuePtr(), sizeof(double) * (size_t)m->nonZeros());
+}
+void mmgh_fs_get_normals(void *gp, double *nx, double *ny)
+{
+    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
+    for (size_t i = 0; i < g->normalVecs_.size(); ++i) { nx[i] = std::get<0>(g->normalVecs_[i]); ny[i] = std::get<1>(g->normalVecs_[i]); }
+}
+// which: 0 u, 1 v, 2 u_hat, 3 v_hat
+static mmgh::Vec *fs_vec(FractionalStepGrid *g, int which) { return which == 0 ? g->u : (which == 1 ? g->v : (which == 2 ? g->u_hat : g->v_hat)); }
+int mmgh_fs_get_vec(void *gp, int which, double *w)
+{
+    return guard([&]() { mmgh::Vec *x = fs_vec(static_cast<FractionalStepGrid *>(gp), which); std::memcpy(w, x->data(), sizeof(double) * (size_t)x->rows()); });
+}
+void mmgh_fs_set_vec(void *gp, int which, const double *w)
+{
+    std::vector<double> &x = fs_vec(static_cast<FractionalStepGrid *>(gp), which)->host_mut();
+    std::memcpy(x.data(), w, sizeof(double) * x.size());
+}
+void mmgh_fs_prescribe_soln(void *gp) { static_cast<FractionalStepGrid *>(gp)->prescribe_soln(); }
+void mmgh_fs_set_uv_bound(void *gp) { static_cast<FractionalStepGrid *>(gp)->set_uv_bound(); }
+int mmgh_fs_calc_hat(void *gp) { return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->calc_u_hat(); g->calc_v_hat(); }); }
+int mmgh_fs_set_ppe_source(void *gp) { return guard([&]() { static_cast<FractionalStepGrid *>(gp)->set_ppe_source(); }); }
+int mmgh_fs_push_inhomog(void *gp) { return guard([&]() { static_cast<FractionalStepGrid *>(gp)->push_inhomog_to_rhs(); }); }
+int mmgh_fs_correct(void *gp) { return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->correct_u(); g->correct_v(); }); }
+int mmgh_fs_residual(void *gp, double *r) { return guard([&]() { *r = static_cast<FractionalStepGrid *>(gp)->fs_residual(); }); }
 
 // ---- domain decomposition ----------------------------------------------------------------
 void mmgh_grid_partition_slabs(void *gp, int nparts, int *part)

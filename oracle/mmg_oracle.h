@@ -77,4 +77,22 @@ void orc_sor_hybrid(orc_level *g, const int *part, int nparts, int nsweeps);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- fractional-step grid (fractionalStepGrid.cpp:101-154), SURVEY 8f-1 -------------- */
+#ifdef __cplusplus
+extern "C" {
 #endif
+typedef struct { int rows; const int *rowptr; const int *col; const double *val; } orc_csr;
+void orc_csr_spmv(const orc_csr *m, const double *x, double *y);
+void orc_fs_calc_hat(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *lap, const double *u,
+                     const double *v, double dt, double mu, double rho, double *u_hat, double *v_hat);
+void orc_fs_set_ppe_source(int n, const orc_csr *dx, const orc_csr *dy, const double *u, const double *v,
+                           const double *u_hat, const double *v_hat, double dt, double rho, const int *bpts,
+                           int nbpts, const double *nx, const double *ny, double *source);
+void orc_fs_correct(int n, const orc_csr *dx, const orc_csr *dy, const double *p, const double *u_hat,
+                    const double *v_hat, double dt, double rho, double *u, double *v);
+double orc_fs_residual(int n, const double *u, const double *u_hat);
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMG_ORACLE_H */

@@ -26,6 +26,10 @@ class _Level(C.Structure):
                 ("bptr", _ip), ("bpts", _ip), ("bvals", _dp)]
 
 
+class _Csr(C.Structure):
+    _fields_ = [("rows", C.c_int), ("rowptr", _ip), ("col", _ip), ("val", _dp)]
+
+
 class _Csc(C.Structure):
     _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("colptr", _ip), ("rowidx", _ip), ("val", _dp)]
 
@@ -66,6 +70,13 @@ def lib(fast=False):
         L.orc_fix_vector_bound_coarse.argtypes = [C.POINTER(_Level), _dp]
         L.orc_csc_spmv.argtypes = [C.POINTER(_Csc), _dp, _dp]
         L.orc_sor_hybrid.argtypes = [C.POINTER(_Level), _ip, C.c_int, C.c_int]
+        pc = C.POINTER(_Csr)
+        L.orc_fs_calc_hat.argtypes = [C.c_int, pc, pc, pc, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_fs_set_ppe_source.argtypes = [C.c_int, pc, pc, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, C.c_int,
+                                            _dp, _dp, _dp]
+        L.orc_fs_correct.argtypes = [C.c_int, pc, pc, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
+        L.orc_fs_residual.argtypes = [C.c_int, _dp, _dp]
+        L.orc_fs_residual.restype = C.c_double
         _libs[name] = L
     return _libs[name]
 
@@ -224,3 +235,36 @@ def ref_lib():
     L.ref_shifting_scaling.argtypes = [_dp, C.c_int, _dp, _dp]
     L.ref_rcm.argtypes = [_ip, _ip, C.c_int, _ip]
     return L
+
+
+class FracStep:
+    """fractionalStepGrid.cpp:101-154 on plain arrays (oracle)."""
+
+    def __init__(self, n, dx, dy, lap, nx, ny, bpts):
+        self.n = int(n)
+        self._m = []
+        for (rp, col, val) in (dx, dy, lap):
+            rp, col, val = _i(rp), _i(col), _d(val)
+            st = _Csr()
+            st.rows, st.rowptr, st.col, st.val = self.n, _pi(rp), _pi(col), _pd(val)
+            self._m.append((st, rp, col, val))
+        self.nx, self.ny, self.bpts = _d(nx), _d(ny), _i(bpts)
+        self.u, self.v = np.zeros(self.n), np.zeros(self.n)
+        self.u_hat, self.v_hat = np.zeros(self.n), np.zeros(self.n)
+
+    def calc_hat(self, dt, mu, rho):
+        lib().orc_fs_calc_hat(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), C.byref(self._m[2][0]),
+                              _pd(self.u), _pd(self.v), dt, mu, rho, _pd(self.u_hat), _pd(self.v_hat))
+
+    def set_ppe_source(self, source, dt, rho):
+        lib().orc_fs_set_ppe_source(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), _pd(self.u), _pd(self.v),
+                                    _pd(self.u_hat), _pd(self.v_hat), dt, rho, _pi(self.bpts), len(self.bpts),
+                                    _pd(self.nx), _pd(self.ny), _pd(source))
+
+    def correct(self, p, dt, rho):
+        p = _d(p)
+        lib().orc_fs_correct(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), _pd(p), _pd(self.u_hat),
+                             _pd(self.v_hat), dt, rho, _pd(self.u), _pd(self.v))
+
+    def residual(self):
+        return float(lib().orc_fs_residual(self.n, _pd(self.u), _pd(self.u_hat)))

@@ -438,6 +438,20 @@ class Grid:
             for p in range(rowptr[i], rowptr[i + 1]):
                 self.source[i] -= val[p] * src[col[p]] / self.diags[col[p]]
 
+    # fractionalStepGrid.cpp:60-100 -- D_x, D_y and the plain Laplacian with a row for EVERY point
+    def build_fs_matrices(self):
+        n = self.n
+        out = []
+        for kind in ("dx", "dy", "lap"):
+            trip = []
+            for i in range(n):
+                w, nb = (self.deriv_weights(i, 0) if kind == "dx" else
+                         self.deriv_weights(i, 1) if kind == "dy" else self.laplace_weights(i))
+                for j, c in enumerate(nb):
+                    trip.append((i, c, w[j]))
+            out.append(csr_from_triplets(n, n, trip))
+        return out
+
     # ---- flattened views for the C oracle / the C-ABI -----------------------
     def boundary_arrays(self):
         btype = np.array([b.type for b in self.boundaries], dtype=np.int32)

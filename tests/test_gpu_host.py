@@ -137,3 +137,39 @@ def test_baseline_config1_1e4_points_3_levels(host):
     mg.vcycles(5)
     ro = [om.vcycle() for _ in range(5)]
     assert np.allclose(mg.residuals[-5:], ro, rtol=1e-10, atol=FLOOR)
+
+
+def test_fractional_step_grid_ops_match_oracle(host):
+    """fractionalStepGrid.cpp:101-154 (predictor, PPE source, corrector, fs_residual) on the
+    device through the host FractionalStepGrid class vs the C oracle on the same operators,
+    following one time step of FractionalStepSim.cpp:130-147."""
+    pts = host.square_cloud(29, seed=8)
+    g = host.FracStepGrid.create(pts, polydeg=3, dt=2e-4, mu=0.025, rho=1.0, ordering=host.ORDER_MC, tile_points=128)
+    o = g.oracle()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    rng = np.random.default_rng(0)
+    u0 = g.vec(0) + 1e-3 * rng.standard_normal(n)
+    v0 = g.vec(1) + 1e-3 * rng.standard_normal(n)
+    g.set_vec(0, u0)
+    g.set_vec(1, v0)
+    g.set_uv_bound()
+    o.u[:], o.v[:] = g.vec(0), g.vec(1)
+    g.calc_hat()
+    o.calc_hat(g.dt, g.mu, g.rho)
+    assert H.rel_err(g.vec(2), o.u_hat) < 1e-12 and H.rel_err(g.vec(3), o.v_hat) < 1e-12
+    src_o = g.source().copy()
+    g.set_ppe_source()
+    o.set_ppe_source(src_o, g.dt, g.rho)
+    assert np.abs(g.source() - src_o).max() <= 1e-11 * np.abs(src_o).max()
+    g.push_inhomog_to_rhs()
+    # pressure solve with the level's own smoother, then the corrector
+    lvl = H.oracle_level(g.level_arrays())
+    for _ in range(3):
+        g.sor()
+        lvl.sor()
+    assert H.rel_err(g.values(), lvl.x) < 1e-12
+    g.correct()
+    o.correct(lvl.x[:n], g.dt, g.rho)
+    assert H.rel_err(g.vec(0), o.u) < 1e-12 and H.rel_err(g.vec(1), o.v) < 1e-12
+    assert abs(g.fs_residual() - o.residual()) <= 1e-12 * o.residual()

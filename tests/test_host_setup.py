@@ -160,3 +160,27 @@ def test_3d_rbf_weights_reproduce_polynomials(host):
     A = sp.csr_matrix((val, col, rowptr), shape=(len(u), len(u)))
     lap = A @ u
     assert np.abs(lap[flags == 0] - 4.0).max() < 1e-6
+
+
+def test_fracstep_operators_match_numpy_oracle_and_kovasznay(host):
+    """FractionalStepGrid setup (fractionalStepGrid.cpp:60-100): D_x, D_y, Laplacian rows for
+    every point match the numpy restatement; applied to the Kovasznay field they approximate
+    the analytic derivatives (the reference's check_derivs, FractionalStepSim.cpp:80-103)."""
+    from oracle import setup_oracle as so
+    pts = host.square_cloud(21, seed=4)
+    g = host.FracStepGrid.create(pts, polydeg=3, ordering=host.ORDER_RCM)
+    xyz, flags = g.points()
+    og = so.gen_grid_neumann_square(pts, so.make_props(3))   # same cloud, same RCM order
+    assert np.array_equal(xyz, og.points)
+    want = og.build_fs_matrices()
+    for which in range(3):
+        rp, col, val = g.op(which)
+        assert np.array_equal(rp, want[which][0]) and np.array_equal(col, want[which][1])
+        assert np.abs(val - want[which][2]).max() <= 1e-7 * np.abs(want[which][2]).max()
+    import scipy.sparse as sp
+    re = 1.0 / 0.025
+    lam = 0.5 * re - np.sqrt(0.25 * re * re + 4 * np.pi ** 2)
+    u = 1 - np.exp(lam * xyz[:, 0]) * np.cos(2 * np.pi * xyz[:, 1])
+    dx = sp.csr_matrix((g.op(0)[2], g.op(0)[1], g.op(0)[0]), shape=(len(u), len(u)))
+    exact = -lam * np.exp(lam * xyz[:, 0]) * np.cos(2 * np.pi * xyz[:, 1])
+    assert np.abs(dx @ u - exact)[flags == 0].mean() < 5e-2
