@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--persistent", type=int, default=1,
-                    help="0: one launch per phase; 1: one dependency-driven launch per sweep; 2: same with agent fences")
+                    help="0: one launch per phase; 1: automatic (single dependency-driven launch when a sweep needs "
+                         "several residency rounds); 4: always single launch; 2: single launch with agent fences")
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
     return ap.parse_args()
@@ -204,7 +205,7 @@ def main():
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
                 "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
-                "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": a.persistent,
+                "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches == sweeps_timed),
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if world == 1 else
                                f"domain decomposition: {world} x-slabs, RCCL ghost exchange once per sweep "
@@ -214,7 +215,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "sweep_persistent_kernel<L,MAXP>" if a.persistent else "tile_kernel<L,MODE_SOR,MAXP>",
+                "kernel": "sweep_persistent_kernel<L,MAXP>" if launches == sweeps_timed else "tile_kernel<L,MODE_SOR,MAXP>",
                 "launches": launches,
                 "avg_launch_us": kern_ms * 1e3 / launches,
                 "algorithmic_bytes_per_row": b_sor(stencil),

@@ -21,9 +21,11 @@ def main():
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--polydeg", type=int, default=4)
+    ap.add_argument("--persistent", type=int, default=1)
     ap.add_argument("--oracle-cycles", type=int, default=0, help="also run this many cycles on the CPU oracle")
     a = ap.parse_args()
-    from meshlessmultigridpoisson_amd import _host
+    from meshlessmultigridpoisson_amd import _capi, _host
+    _capi.set_option("persistent_sweep", a.persistent)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
     clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]

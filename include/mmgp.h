@@ -91,7 +91,9 @@ int mmg_set_device(int device);
  * thread's handles; NULL selects the library's own non-blocking stream. */
 int mmg_set_stream(void *hip_stream);
 int mmg_synchronize(void);
-/* "persistent_sweep" (0/1): relax a level with ONE launch per sweep -- resident
+/* "persistent_sweep": 0 one launch per phase; 1 (default) automatic -- single launch when a
+ * sweep needs more than one residency round of tiles; 4 always single launch; 2 single launch
+ * with full agent-scope fences per tile (slow, for validation).  Single launch = resident
  * wavefronts draw tiles in phase order and start each as soon as the earlier tiles
  * it is coupled to have published their values -- instead of one launch per phase.
  * Same arithmetic, same order of coupled rows (exact); removes the per-phase

@@ -28,7 +28,7 @@ def _need_gpu():
     assert _capi.device_count() >= 1, "no HIP device visible: libmmgp has no CPU fallback"
 
 
-@pytest.fixture(params=[1, 0], ids=["single-launch", "per-phase"])
+@pytest.fixture(params=[4, 0], ids=["single-launch", "per-phase"])
 def sweep_mode(request):
     """Both relaxation drivers: the dependency-driven single launch (default) and one
     launch per phase."""
@@ -252,7 +252,7 @@ def test_persistent_single_launch_sweep_matches_oracle(name, tile, L):
     case = H.load_case(name)
     la = H.level_arrays(case, case["nlevels"] - 1)
     o = H.oracle_level(la)
-    _capi.set_option("persistent_sweep", 1)
+    _capi.set_option("persistent_sweep", 4)
     try:
         d = H.device_level(la, tile_size=tile, lanes_per_row=L)
         assert d.info()["n_phases"] > 1
@@ -277,7 +277,7 @@ def test_persistent_sweep_3d_many_tiles():
     rng = np.random.default_rng(2)
     la["b0"] = rng.standard_normal(la["a_size"])
     o = H.oracle_level(la)
-    _capi.set_option("persistent_sweep", 1)
+    _capi.set_option("persistent_sweep", 4)
     try:
         d = _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], 0, 1.4, 5, la["btype"], la["bptr"],
                         la["bpts"], la["bvals"], x=la["x0"], b=la["b0"], tile_ptr=g.tile_ptr(), lanes_per_row=2)
