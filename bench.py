@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--persistent", type=int, default=1,
                     help="0: one launch per phase; 1: automatic (single dependency-driven launch when a sweep needs "
                          "several residency rounds); 4: always single launch; 2: single launch with agent fences")
+    ap.add_argument("--force-dd", action="store_true",
+                    help="take the domain-decomposition code path (slab-local system, RCCL communicator, exchange "
+                         "lists) even with one rank -- rehearsal of the N>1 path on a 1-GPU box")
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
     return ap.parse_args()
@@ -87,7 +90,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or (a.force_dd and "RANK" in os.environ):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -107,7 +110,8 @@ def main():
         cus, lds = 0, 0
     if a.tile <= 0:
         a.tile = _capi.auto_tile_points(a.nside ** a.dim, a.dim, stencil, a.lanes, cus, lds)
-    if world == 1:
+    dd = world > 1 or a.force_dd
+    if not dd:
         pts = _host.box_cloud(a.nside, a.dim, seed=12345)
         grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC,
                                         tile_points=a.tile, lanes_per_row=a.lanes)
@@ -120,13 +124,16 @@ def main():
         n_owned, lgid, gown = grid.local_map()
 
         def all_gather_object(obj):
+            if dist is None:
+                return [obj]
             out = [None] * world
             dist.all_gather_object(out, obj)
             return out
 
         nbr, sp, si, rp = _host.build_exchange_lists(rank, n_owned, lgid, gown, all_gather_object)
         ids = [_capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(ids, src=0)
         _capi.comm_init(rank, world, ids[0])
     sz = grid.sizes()
     rng = np.random.default_rng(7 + rank)
@@ -134,7 +141,7 @@ def main():
     rhs[n_owned:] = 0.0
     grid.set_source(rhs)
     lv = _capi.Level.borrow(grid.device_level(), sz["n"], sz["a_size"])
-    if world > 1:
+    if dd:
         lv.set_exchange(n_owned, nbr, sp, si, rp)
     info = lv.info()
     t_setup = time.perf_counter() - t_setup
@@ -207,7 +214,7 @@ def main():
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
                 "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches == sweeps_timed),
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
-                "parallelism": "single" if world == 1 else
+                "parallelism": "single" if not dd else
                                f"domain decomposition: {world} x-slabs, RCCL ghost exchange once per sweep "
                                f"(block-hybrid Gauss-Seidel), {sz['n'] - n_owned} ghost values per rank",
                 "setup_seconds": round(t_setup, 1),
@@ -223,12 +230,13 @@ def main():
         }
         if verify is not None:
             out["config"]["persistent_vs_phase_launches"] = verify
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(grid, stencil, a.cpu_seconds)
         print(json.dumps(out))
+    if dd:
+        _capi.comm_finalize()
     if dist is not None:
         dist.barrier()
-        _capi.comm_finalize()
         dist.destroy_process_group()
 
 
