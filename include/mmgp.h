@@ -163,7 +163,10 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
  * ghosts are refreshed once before every sweep and before every residual, i.e. a
  * row sees the current sweep's values of its own rank and the previous sweep's
  * values of the others -- the schedule oracle/mmg_oracle.c:orc_sor_hybrid states.
- * Norms are all-reduced (2 doubles).  Neumann levels are not distributed yet. */
+ * Also refreshed: x before bound_eval_neumann and before a prolongation reads the coarse level,
+ * the residual vector before a restriction reads it.  All-reduces: the residual norms (2
+ * doubles) and, on Neumann levels, the sum behind the replicated multiplier unknown (1 double
+ * per sweep and per residual). */
 int mmg_comm_get_unique_id(char *id128);   /* 128 bytes; the caller broadcasts rank 0's */
 int mmg_comm_init(int rank, int nranks, const char *id128);
 int mmg_comm_finalize(void);

@@ -234,7 +234,8 @@ class Level:
 
     def set_exchange(self, n_owned, nbr_rank, send_ptr, send_idx, recv_ptr):
         nbr, sp, si, rp = _i(nbr_rank), _i(send_ptr), _i(send_idx), _i(recv_ptr)
-        check(lib().mmg_level_set_exchange(self.h, int(n_owned), len(nbr), _pi(nbr), _pi(sp), _pi(si), _pi(rp)))
+        check(lib().mmg_level_set_exchange(self.h, int(n_owned), len(nbr), _pi(nbr), sp.ctypes.data_as(_ip),
+                                           si.ctypes.data_as(_ip) if si.size else None, rp.ctypes.data_as(_ip)))
 
     def exchange(self):
         check(lib().mmg_level_exchange(self.h))

@@ -87,6 +87,9 @@ def lib():
                   "mmgh_fs_push_inhomog", "mmgh_fs_correct"):
             getattr(L, f).argtypes = [vp]
         L.mmgh_fs_residual.argtypes = [vp, _dp]
+        L.mmgh_mg_extract_subdomain.restype = vp
+        L.mmgh_mg_extract_subdomain.argtypes = [vp, C.c_int, C.c_int]
+        L.mmgh_mg_level_part.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_grid_partition_slabs.argtypes = [vp, C.c_int, _ip]
         L.mmgh_grid_extract_subdomain.restype = vp
         L.mmgh_grid_extract_subdomain.argtypes = [vp, _ip, C.c_int]
@@ -377,6 +380,35 @@ class Multigrid:
         if getattr(self, "h", None) and _lib is not None:
             _lib.mmgh_mg_destroy(self.h)
             self.h = None
+
+    @classmethod
+    def _from_handle(cls, h, omega, iters):
+        self = cls.__new__(cls)
+        self.h, self.omega, self.iters, self.residuals = h, omega, iters, []
+        return self
+
+    def extract_subdomain(self, nparts, rank):
+        """Rank's sub-domain of every level + the local rows of the transfers (host C++)."""
+        h = lib().mmgh_mg_extract_subdomain(self.h, int(nparts), int(rank))
+        if not h:
+            raise HostError(_err())
+        return Multigrid._from_handle(h, self.omega, self.iters)
+
+    def level_part(self, l, nparts):
+        part = np.zeros(self.grid(l).sizes()["n"], dtype=np.int32)
+        lib().mmgh_mg_level_part(self.h, l, int(nparts), part.ctypes.data_as(_ip))
+        return part
+
+    def setup_exchange(self, rank, all_gather_object):
+        """Distributed run: register every level's ghost exchange with the device
+        (mmg_level_set_exchange).  Needs mmg_comm_init to have been called."""
+        from . import _capi
+        for l in range(self.nlevels):
+            g = self.grid(l)
+            no, gid, gown = g.local_map()
+            nbr, sp, si, rp = build_exchange_lists(rank, no, gid, gown, all_gather_object)
+            s = g.sizes()
+            _capi.Level.borrow(g.device_level(), s["n"], s["a_size"]).set_exchange(no, nbr, sp, si, rp)
 
     @property
     def nlevels(self):

@@ -218,6 +218,7 @@ struct mmg_level {
     std::vector<int> nbr, send_ptr, recv_ptr;
     DevBuf<int32_t> send_idx;
     DevBuf<double> sendbuf;
+    DevBuf<double> scalS;  // all-reduced sum of the non-Neumann x (multiplier row)
 };
 
 struct mmg_transfer {
@@ -264,16 +265,19 @@ int build_gather_plan(const CsrView &A, const std::vector<int32_t> &rows, int L,
 
 // refresh the ghost copies: pack owned boundary-layer values, one grouped send/recv
 // per neighbour straight into the ghost segment of x (ghosts are grouped by owner)
-int exchange(mmg_level *lv)
+int exchange_vec(mmg_level *lv, double *vec);
+int exchange(mmg_level *lv) { return exchange_vec(lv, lv->x.p); }
+
+int exchange_vec(mmg_level *lv, double *vec)
 {
     if (!lv->distributed || lv->nbr.empty()) return MMG_OK;
     if (!g_rccl.comm) return fail(MMG_ERR_COMM, "mmg_comm_init has not been called");
-    HIPC(launch_gather(lv->sendbuf.p, lv->x.p, lv->send_idx.p, (int)lv->send_idx.n, g_stream));
+    HIPC(launch_gather(lv->sendbuf.p, vec, lv->send_idx.p, (int)lv->send_idx.n, g_stream));
     NCCLC(g_rccl.GroupStart());
     for (size_t k = 0; k < lv->nbr.size(); ++k) {
         const int ns = lv->send_ptr[k + 1] - lv->send_ptr[k], nr = lv->recv_ptr[k + 1] - lv->recv_ptr[k];
         if (ns > 0) NCCLC(g_rccl.Send(lv->sendbuf.p + lv->send_ptr[k], (size_t)ns, kNcclDouble, lv->nbr[k], g_rccl.comm, g_stream));
-        if (nr > 0) NCCLC(g_rccl.Recv(lv->x.p + lv->n_owned + lv->recv_ptr[k], (size_t)nr, kNcclDouble, lv->nbr[k], g_rccl.comm, g_stream));
+        if (nr > 0) NCCLC(g_rccl.Recv(vec + lv->n_owned + lv->recv_ptr[k], (size_t)nr, kNcclDouble, lv->nbr[k], g_rccl.comm, g_stream));
     }
     NCCLC(g_rccl.GroupEnd());
     return MMG_OK;
@@ -289,6 +293,12 @@ bool use_single_launch(const mmg_level *lv)
     if (g_persistent_sweep == 0) return false;
     if (g_persistent_sweep == 1) return lv->A.n_tiles > lv->workers;
     return true;
+}
+
+int allreduce_sum(double *p, int count)
+{
+    if (g_rccl.comm && g_rccl.nranks > 1) NCCLC(g_rccl.AllReduce(p, p, (size_t)count, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
+    return MMG_OK;
 }
 
 int sweep_once(mmg_level *lv)
@@ -321,7 +331,12 @@ int sweep_once(mmg_level *lv)
         }
     }
     if (lv->neumann) {
-        if (lv->A.exact) HIPC(launch_mult_update_exact(lv->x.p, lv->b.p, lv->n, lv->flags8.p, lv->omega, g_stream));
+        if (lv->distributed) {  // K2 across ranks: local partial sums -> one double -> ncclAllReduce -> update
+            HIPC(launch_sum_partials(lv->partX.p, lv->A.n_tiles, lv->scalS.p, g_stream));
+            int rc = allreduce_sum(lv->scalS.p, 1);
+            if (rc) return rc;
+            HIPC(launch_mult_apply(lv->x.p, lv->b.p, lv->n, lv->scalS.p, lv->omega, g_stream));
+        } else if (lv->A.exact) HIPC(launch_mult_update_exact(lv->x.p, lv->b.p, lv->n, lv->flags8.p, lv->omega, g_stream));
         else HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
     }
     return MMG_OK;
@@ -340,6 +355,10 @@ int check_sync_error(mmg_level *lv)
 int bound_eval(mmg_level *lv)
 {
     if (lv->B.empty()) return MMG_OK;
+    if (lv->distributed) {  // Neumann rows read interior values owned by neighbours: current ones
+        const int rc = exchange(lv);
+        if (rc) return rc;
+    }
     TileArgs a{};
     a.p = lv->B.dev;
     a.in = lv->x.p;
@@ -397,6 +416,14 @@ int residual_dev(mmg_level *lv, bool norms)
     }
     HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
     if (norms) HIPC(launch_abs_sum(lv->b.p, lv->a_size, lv->partBn.p, g_stream));
+    if (lv->distributed && lv->neumann) {
+        HIPC(launch_sum_partials(lv->partX.p, lv->A.n_tiles, lv->scalS.p, g_stream));
+        const int rc = allreduce_sum(lv->scalS.p, 1);
+        if (rc) return rc;
+        HIPC(launch_resid_finalize_dist(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
+                                        lv->partBn.p, norms ? lv->n_absb : 0, lv->scalS.p, lv->x.p, lv->b.p, lv->r.p,
+                                        lv->n, lv->neumann, g_rccl.rank == 0, lv->scal.p, g_stream));
+    } else
     HIPC(launch_resid_finalize(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
                                lv->partBn.p, norms ? lv->n_absb : 0, lv->partX.p, lv->A.n_tiles, lv->x.p, lv->b.p,
                                lv->r.p, lv->n, lv->neumann, lv->scal.p, g_stream));
@@ -451,6 +478,7 @@ int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
     if (R->rows != coarse->n || R->cols != fine->n) return fail(MMG_ERR_INVALID, "restrict: shape mismatch");
     int rc = residual_dev(fine, false);
     if (rc) return rc;
+    if ((rc = exchange_vec(fine, fine->r.p))) return rc;  // K6: fine-residual halo
     TileArgs a{};
     a.p = R->all.dev;
     a.n_list = R->all.n_tiles;
@@ -490,6 +518,10 @@ int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
             plan = pg.get();
             P->masked.emplace_back(fine, std::move(pg));
         }
+    }
+    {
+        const int rc = exchange(coarse);  // K7: coarse-correction halo
+        if (rc) return rc;
     }
     TileArgs a{};
     a.p = plan->dev;
@@ -968,7 +1000,7 @@ int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const i
                            const int *send_idx, const int *recv_ptr)
 {
     if (!lv || n_owned_points < 0 || n_owned_points > lv->n || n_nbr < 0) return fail(MMG_ERR_INVALID, "set_exchange: bad argument");
-    if (lv->neumann) return fail(MMG_ERR_UNSUPPORTED, "distributed Neumann levels (all-reduced multiplier row) are not implemented");
+    if (lv->A.exact) return fail(MMG_ERR_UNSUPPORTED, "exact_arithmetic levels cannot be distributed");
     if (n_nbr > 0 && (!nbr_rank || !send_ptr || !recv_ptr)) return fail(MMG_ERR_INVALID, "set_exchange: null lists");
     lv->nbr.assign(nbr_rank, nbr_rank + n_nbr);
     lv->send_ptr.assign(send_ptr, send_ptr + (n_nbr ? n_nbr + 1 : 0));
@@ -979,6 +1011,7 @@ int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const i
         if (send_idx[k] < 0 || send_idx[k] >= n_owned_points) return fail(MMG_ERR_INVALID, "set_exchange: send index is not an owned point");
     HIPC(lv->send_idx.upload(send_idx, (size_t)ns));
     HIPC(lv->sendbuf.alloc((size_t)std::max(ns, 1)));
+    HIPC(lv->scalS.alloc(1));
     lv->n_owned = n_owned_points;
     lv->distributed = true;
     return MMG_OK;

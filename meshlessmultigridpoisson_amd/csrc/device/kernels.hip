@@ -557,9 +557,52 @@ __global__ __launch_bounds__(256) void k_mult_update(double *x, const double *b,
     }
 }
 
+__global__ void k_mult_apply(double *x, const double *b, int n, const double *S, double omega)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double xi = b[n] - *S;
+    xi *= omega / 1.0;
+    xi += (1.0 - omega) * x[n];
+    x[n] = xi;
+}
+
+__global__ __launch_bounds__(256) void k_resid_finalize_dist(const double *pa, int na, const double *pb, int nb,
+                                                             const double *pbn, int nbn, const double *S, const double *x,
+                                                             const double *b, double *r, int n, int neumann,
+                                                             int count_shared, double *out2)
+{
+    __shared__ double sh[256];
+    double nr = block_sum_256(pa, na, sh);
+    if (nb > 0) nr += block_sum_256(pb, nb, sh);
+    double nbsum = block_sum_256(pbn, nbn, sh);
+    if (threadIdx.x == 0) {
+        if (neumann) {
+            const double rn = b[n] - (*S + x[n]);
+            r[n] = rn;
+            if (count_shared) nr += fabs(rn);
+            else if (nbn > 0) nbsum -= fabs(b[n]);  // the replicated multiplier entry counts once
+        }
+        out2[0] = nr;
+        out2[1] = nbsum;
+    }
+}
+
 constexpr int kAbsBlock = 256;
 constexpr int kAbsPerBlock = 256 * 16;
 }  // namespace
+hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mult_apply, dim3(1), dim3(64), 0, s, x, b, n, S, omega);
+    return hipGetLastError();
+}
+hipError_t launch_resid_finalize_dist(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
+                                      const double *S, const double *x, const double *b, double *r, int n, int neumann,
+                                      int count_shared, double *out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_resid_finalize_dist, dim3(1), dim3(256), 0, s, pa, na, pb, nb, pbn, nbn, S, x, b, r, n, neumann,
+                       count_shared, out2);
+    return hipGetLastError();
+}
 int abs_sum_blocks(long long n) { return (int)((n + kAbsPerBlock - 1) / kAbsPerBlock); }
 namespace {
 

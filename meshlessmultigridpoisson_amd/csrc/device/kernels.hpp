@@ -69,6 +69,13 @@ hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals
 // x[n] <- (1-w) x[n] + w (b[n] - sum(partial))            (grid.cpp:118-141, row N)
 hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial,
                               double omega, hipStream_t s);
+// x[n] <- (1-w) x[n] + w (b[n] - *S)   (distributed: *S is the all-reduced sum)
+hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, hipStream_t s);
+// distributed variant of launch_resid_finalize: S is the all-reduced sum of the non-Neumann x;
+// only `count_shared` ranks (rank 0) add the multiplier row and b[n] to the norms
+hipError_t launch_resid_finalize_dist(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
+                                      const double *S, const double *x, const double *b, double *r, int n, int neumann,
+                                      int count_shared, double *out2, hipStream_t s);
 // partial[block] = sum |v|
 int abs_sum_blocks(long long n);
 hipError_t launch_abs_sum(const double *v, long long n, double *partial, hipStream_t s);

@@ -458,9 +458,8 @@ vector<int> Grid::partition_slabs(int nparts)
     return part;
 }
 
-Grid *Grid::extract_subdomain(const vector<int> &part, int rank)
+Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts)
 {
-    if (neumannFlag_) throw std::invalid_argument("extract_subdomain: Dirichlet grids only");
     const int n = (int)points_.size();
     if ((int)part.size() != n) throw std::invalid_argument("extract_subdomain: part size mismatch");
     const int *rp = laplaceMat_->outerIndexPtr();
@@ -470,23 +469,26 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank)
     for (int i = 0; i < n; ++i)
         if (part[(size_t)i] == rank) { local[(size_t)i] = (int)owned.size(); owned.push_back(i); }
     vector<std::pair<int, int>> ghosts;  // (owner, global index)
+    auto want = [&](int c) {
+        if (c < n && part[(size_t)c] != rank && local[(size_t)c] == -1) { local[(size_t)c] = -2; ghosts.emplace_back(part[(size_t)c], c); }
+    };
     for (int i : owned)
-        for (int p = rp[i]; p < rp[i + 1]; ++p) {
-            const int c = col[p];
-            if (part[(size_t)c] != rank && local[(size_t)c] == -1) { local[(size_t)c] = -2; ghosts.emplace_back(part[(size_t)c], c); }
-        }
+        for (int p = rp[i]; p < rp[i + 1]; ++p) want(col[p]);
+    if (extra_ghosts)
+        for (int c : *extra_ghosts) want(c);
     std::sort(ghosts.begin(), ghosts.end());
-    const int no = (int)owned.size(), ng = (int)ghosts.size();
+    const int no = (int)owned.size(), ng = (int)ghosts.size(), nl = no + ng;
     for (int k = 0; k < ng; ++k) local[(size_t)ghosts[(size_t)k].second] = no + k;
 
-    vector<Point> pts((size_t)(no + ng));
-    VectorXd src((size_t)(no + ng));
+    vector<Point> pts((size_t)nl);
+    VectorXd src((size_t)(nl + (neumannFlag_ ? 1 : 0)));
     for (int k = 0; k < no; ++k) { pts[(size_t)k] = points_[(size_t)owned[(size_t)k]]; src(k) = source_.coeff(owned[(size_t)k]); }
     for (int k = 0; k < ng; ++k) pts[(size_t)(no + k)] = points_[(size_t)ghosts[(size_t)k].second];
+    if (neumannFlag_) src(nl) = source_.coeff(n);
     vector<Boundary> bnds;
     for (const Boundary &b : boundaries_) {
         Boundary nb;
-        nb.type = b.type;
+        nb.type = b.type;  // kept even when empty: a rank without boundary points still solves the Neumann system
         for (size_t j = 0; j < b.bcPoints.size(); ++j)
             if (part[(size_t)b.bcPoints[j]] == rank) {
                 nb.bcPoints.push_back(local[(size_t)b.bcPoints[j]]);
@@ -499,24 +501,41 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank)
     g->implicitFlag_ = implicitFlag_;
     g->lanes_per_row_ = lanes_per_row_;
     g->tile_size_ = tile_size_;
-    for (int k = 0; k < no; ++k) g->bcFlags_[(size_t)k] = bcFlags_[(size_t)owned[(size_t)k]];
-    for (int k = 0; k < ng; ++k) g->bcFlags_[(size_t)(no + k)] = kGhost;
+    for (int k = 0; k < no; ++k) {
+        g->bcFlags_[(size_t)k] = bcFlags_[(size_t)owned[(size_t)k]];
+        g->normalVecs_[(size_t)k] = normalVecs_[(size_t)owned[(size_t)k]];
+        g->values_->coeffRef(k) = values_->coeff(owned[(size_t)k]);
+    }
+    for (int k = 0; k < ng; ++k) {
+        g->bcFlags_[(size_t)(no + k)] = kGhost;
+        g->values_->coeffRef(no + k) = values_->coeff(ghosts[(size_t)k].second);
+    }
+    if (neumannFlag_) g->values_->coeffRef(nl) = values_->coeff(n);
     g->nOwned_ = no;
-    g->origIndex_.resize((size_t)(no + ng));
+    g->origIndex_.resize((size_t)nl);
     for (int k = 0; k < no; ++k) g->origIndex_[(size_t)k] = owned[(size_t)k];
     for (int k = 0; k < ng; ++k) { g->origIndex_[(size_t)(no + k)] = ghosts[(size_t)k].second; g->ghostOwner_.push_back(ghosts[(size_t)k].first); }
-    // rows of the owned points, columns renumbered (ascending LOCAL order is not required by
-    // libmmgp, but keep the global column order so a row's dot product associates identically)
-    std::vector<int> outer((size_t)(no + ng) + 1, 0), inner;
+    // rows of the owned points with renumbered columns (global multiplier column n -> local nl);
+    // the local multiplier row lists every local non-Neumann point: the device sums the OWNED ones
+    // and all-reduces (mmgp.h "multi-GPU").
+    const int a_loc = nl + (neumannFlag_ ? 1 : 0);
+    std::vector<int> outer((size_t)a_loc + 1, 0), inner;
     std::vector<double> v;
     for (int k = 0; k < no; ++k) {
         const int i = owned[(size_t)k];
-        for (int p = rp[i]; p < rp[i + 1]; ++p) { inner.push_back(local[(size_t)col[p]]); v.push_back(val[p]); }
+        for (int p = rp[i]; p < rp[i + 1]; ++p) { inner.push_back(col[p] == n ? nl : local[(size_t)col[p]]); v.push_back(val[p]); }
         outer[(size_t)k + 1] = (int)inner.size();
     }
-    for (int k = no; k < no + ng; ++k) outer[(size_t)k + 1] = outer[(size_t)k];
+    for (int k = no; k < nl; ++k) outer[(size_t)k + 1] = outer[(size_t)k];
+    if (neumannFlag_) {
+        for (int k = 0; k < nl; ++k)
+            if (g->bcFlags_[(size_t)k] != 2) { inner.push_back(k); v.push_back(1.0); }
+        inner.push_back(nl);
+        v.push_back(1.0);
+        outer[(size_t)nl + 1] = (int)inner.size();
+    }
     delete g->laplaceMat_;
-    g->laplaceMat_ = new SparseRowMajor(no + ng, no + ng, true);
+    g->laplaceMat_ = new SparseRowMajor(a_loc, a_loc, true);
     g->laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(v));
     // tiles: the owned part of every global tile, in order
     if (!tile_ptr_.empty()) {

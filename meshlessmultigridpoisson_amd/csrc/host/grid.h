@@ -105,8 +105,10 @@ public:
     vector<int> partition_slabs(int nparts);
     // The local system of `rank`: its owned points in the current storage order, then the
     // ghost points its rows reference (sorted by owner, then index); matrix rows, boundary
-    // lists, RHS and tile boundaries restricted accordingly.  Dirichlet grids only.
-    Grid *extract_subdomain(const vector<int> &part, int rank);
+    // lists, RHS and tile boundaries restricted accordingly.  `extra_ghosts` (global indices)
+    // are kept as ghosts even if no owned row references them (transfer operators need them).
+    // Neumann grids keep a replicated multiplier unknown (all-reduced on the device).
+    Grid *extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr);
 
     vector<Point> pointIDs_to_vector(const vector<int> &pointIDs);
     vector<int> kNearestNeighbors(Point point, bool neumannFlag, bool pointBCFlag, int k);  // grid.cpp:216-260

@@ -401,6 +401,18 @@ void *mmgh_grid_extract_subdomain(void *gp, const int *part, int rank)
     if (guard([&]() { out = g->extract_subdomain(std::vector<int>(part, part + g->points_.size()), rank); })) return nullptr;
     return out;
 }
+// hierarchy-level decomposition (Multigrid::extract_subdomain); parts of level l via mmgh_mg_level_part
+void *mmgh_mg_extract_subdomain(void *h, int nparts, int rank)
+{
+    Multigrid *out = nullptr;
+    if (guard([&]() { out = static_cast<Multigrid *>(h)->extract_subdomain(nparts, rank, nullptr); })) return nullptr;
+    return out;
+}
+void mmgh_mg_level_part(void *h, int l, int nparts, int *part)
+{
+    auto p = static_cast<Multigrid *>(h)->grids_.at((size_t)l).second->partition_slabs(nparts);
+    std::memcpy(part, p.data(), sizeof(int) * p.size());
+}
 // n_owned, then gid[n_local] and ghost_owner[n_local - n_owned]
 int mmgh_grid_n_owned(void *gp) { return static_cast<Grid *>(gp)->nOwned_; }
 void mmgh_grid_local_map(void *gp, int *gid, int *ghost_owner)

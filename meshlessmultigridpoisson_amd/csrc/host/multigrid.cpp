@@ -164,6 +164,55 @@ void Multigrid::vCycles(int n, float *device_ms)
         if (r >= 0) residuals_.push_back(r);
 }
 
+Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out)
+{
+    const size_t nl = grids_.size();
+    if (nl > 1 && (restrictionMatrices_.size() != nl || prolongMatrices_.size() != nl))
+        throw std::runtime_error("Multigrid::extract_subdomain: buildMatrices() first");
+    vector<vector<int>> part(nl);
+    for (size_t l = 0; l < nl; ++l) part[l] = grids_[l].second->partition_slabs(nparts);
+    // ghost needs of the transfers: columns (points of the INPUT level) touched by owned rows
+    vector<vector<int>> extra(nl);
+    auto need = [&](SparseColMajor *m, const vector<int> &row_part, vector<int> &dst) {
+        if (!m) return;
+        const int *cp = m->outerIndexPtr();
+        const int *ri = m->innerIndexPtr();
+        for (int j = 0; j < m->cols(); ++j)
+            for (int p = cp[j]; p < cp[j + 1]; ++p)
+                if (row_part[(size_t)ri[p]] == rank) { dst.push_back(j); break; }
+    };
+    for (size_t l = 1; l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], extra[l]);  // R_l : level l -> l-1
+    for (size_t l = 0; l + 1 < nl; ++l) need(prolongMatrices_[l], part[l + 1], extra[l]);  // P_l : level l -> l+1
+    Multigrid *out = fracStep_ ? new FractionalStepMultigrid() : new Multigrid();
+    out->printResiduals_ = printResiduals_;
+    vector<vector<int>> loc(nl);
+    for (size_t l = 0; l < nl; ++l) {
+        Grid *g = grids_[l].second->extract_subdomain(part[l], rank, &extra[l]);
+        out->grids_.push_back(std::pair<int, Grid *>((int)l, g));  // keep the level order (sizes may tie)
+        loc[l].assign((size_t)grids_[l].second->getSize(), -1);
+        for (size_t k = 0; k < g->origIndex_.size(); ++k) loc[l][(size_t)g->origIndex_[k]] = (int)k;
+    }
+    auto local_matrix = [&](SparseColMajor *m, size_t lrow, size_t lcol) -> SparseColMajor * {
+        if (!m) return nullptr;
+        vector<Triplet> trip;
+        const int *cp = m->outerIndexPtr();
+        const int *ri = m->innerIndexPtr();
+        const double *v = m->valuePtr();
+        for (int j = 0; j < m->cols(); ++j)
+            for (int p = cp[j]; p < cp[j + 1]; ++p)
+                if (part[lrow][(size_t)ri[p]] == rank) trip.emplace_back(loc[lrow][(size_t)ri[p]], loc[lcol][(size_t)j], v[p]);
+        SparseColMajor *r = new SparseColMajor(out->grids_[lrow].second->getSize(), out->grids_[lcol].second->getSize(), false);
+        r->setFromTriplets(trip.begin(), trip.end());
+        return r;
+    };
+    out->restrictionMatrices_.assign(nl, nullptr);
+    out->prolongMatrices_.assign(nl, nullptr);
+    for (size_t l = 1; l < nl; ++l) out->restrictionMatrices_[l] = local_matrix(restrictionMatrices_[l], l - 1, l);
+    for (size_t l = 0; l + 1 < nl; ++l) out->prolongMatrices_[l] = local_matrix(prolongMatrices_[l], l + 1, l);
+    if (parts_out) *parts_out = part;
+    return out;
+}
+
 double Multigrid::residual()
 {
     ensure_device();

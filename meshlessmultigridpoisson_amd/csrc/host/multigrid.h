@@ -37,6 +37,11 @@ public:
     double residual();                                                    // multigrid.cpp:112-115
     // not in the reference: n cycles back to back without per-cycle host work
     void vCycles(int n, float *device_ms = nullptr);
+    // Domain decomposition of the whole hierarchy (after buildMatrices): every level is cut into
+    // `nparts` x-slabs; the result holds rank's sub-domain of every level (ghosts cover the level
+    // operator AND the columns the local rows of R / P touch) and the local rows of the transfer
+    // matrices.  parts_out[l] receives the owner of every global point of level l.
+    Multigrid *extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out = nullptr);
 
 protected:
     void ensure_device();

@@ -218,6 +218,50 @@ void orc_sor_hybrid(orc_level *g, const int *part, int nparts, int nsweeps)
     free(old);
 }
 
+/* multigrid.cpp:62-110 with Grid::sor replaced by the hybrid sweeps (multi-GPU schedule) */
+double orc_vcycle_hybrid(orc_level *lv, int nl, const orc_csc *R, const orc_csc *P, const int *const *parts,
+                         int nparts)
+{
+    orc_level *fine = &lv[nl - 1];
+    int maxsz = 0;
+    for (int i = 0; i < nl; ++i) if (lv[i].a_size > maxsz) maxsz = lv[i].a_size;
+    double *work = (double *)malloc(sizeof(double) * (size_t)maxsz);
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)maxsz);
+    const double resid = orc_mg_residual(fine, work);
+    orc_bound_eval_neumann(fine);
+    orc_level *curr = fine;
+    for (int i = nl - 1; i > 0; --i) {
+        curr = &lv[i];
+        orc_level *coarse = &lv[i - 1];
+        if (i != nl - 1) memset(curr->x, 0, sizeof(double) * (size_t)curr->a_size);
+        orc_boundary_op(curr, i != nl - 1);
+        orc_sor_hybrid(curr, parts[i], nparts, curr->iters);
+        orc_residual(curr, work);
+        orc_csc_spmv(&R[i], work, tmp);
+        memcpy(coarse->b, tmp, sizeof(double) * (size_t)coarse->n);
+        orc_fix_vector_bound_coarse(coarse, coarse->b);
+        if (curr->neumann_flag) {
+            coarse->b[coarse->a_size - 1] = 0.0;
+            orc_modify_coeff_neumann(coarse, 1);
+        }
+    }
+    orc_boundary_op(curr, 1);
+    curr = &lv[0];
+    memset(curr->x, 0, sizeof(double) * (size_t)curr->a_size);
+    orc_sor_hybrid(curr, parts[0], nparts, curr->iters);
+    orc_sor_hybrid(curr, parts[0], nparts, curr->iters);
+    for (int i = 1; i < nl; ++i) {
+        curr = &lv[i];
+        orc_csc_spmv(&P[i - 1], lv[i - 1].x, tmp);
+        if (!curr->neumann_flag) orc_fix_vector_bound_coarse(curr, tmp);
+        for (int k = 0; k < curr->n; ++k) curr->x[k] += tmp[k];
+        orc_sor_hybrid(curr, parts[i], nparts, curr->iters);
+    }
+    free(work);
+    free(tmp);
+    return resid;
+}
+
 /* ======================================================================================
  * Fractional-step grid: predictor, PPE source, corrector (fractionalStepGrid.cpp:101-154).
  * Eigen semantics restated: sparse*dense products are evaluated into temporaries

@@ -73,6 +73,10 @@ double orc_vcycle(orc_level *levels, int nlevels, const orc_csc *R,
  * sweep's values only for columns of its own part, and the values from the end
  * of the previous sweep for all other parts (ghosts refreshed once per sweep). */
 void orc_sor_hybrid(orc_level *g, const int *part, int nparts, int nsweeps);
+/* V-cycle whose relaxations follow the block-hybrid schedule with parts[l] per level
+ * (everything else -- residuals, transfers, masks -- is schedule-independent). */
+double orc_vcycle_hybrid(orc_level *levels, int nlevels, const orc_csc *R, const orc_csc *P,
+                         const int *const *parts, int nparts);
 
 #ifdef __cplusplus
 }

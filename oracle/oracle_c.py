@@ -70,6 +70,8 @@ def lib(fast=False):
         L.orc_fix_vector_bound_coarse.argtypes = [C.POINTER(_Level), _dp]
         L.orc_csc_spmv.argtypes = [C.POINTER(_Csc), _dp, _dp]
         L.orc_sor_hybrid.argtypes = [C.POINTER(_Level), _ip, C.c_int, C.c_int]
+        L.orc_vcycle_hybrid.restype = C.c_double
+        L.orc_vcycle_hybrid.argtypes = [C.POINTER(_Level), C.c_int, C.POINTER(_Csc), C.POINTER(_Csc), C.POINTER(_ip), C.c_int]
         pc = C.POINTER(_Csr)
         L.orc_fs_calc_hat.argtypes = [C.c_int, pc, pc, pc, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]
         L.orc_fs_set_ppe_source.argtypes = [C.c_int, pc, pc, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _ip, C.c_int,
@@ -216,6 +218,18 @@ class Multigrid:
 
     def residual(self):
         return self.levels[-1].residual_ratio()
+
+    def vcycle_hybrid(self, parts, nparts):
+        """V-cycle with the multi-GPU relaxation schedule; parts[l] = owner of every point of level l."""
+        nl = len(self.levels)
+        lv = (_Level * nl)(*[l.struct() for l in self.levels])
+        Rs = (_Csc * nl)(*[r.struct() for r in self.R])
+        Ps = (_Csc * nl)(*[p.struct() for p in self.P])
+        keep = [_i(p) for p in parts]
+        pp = (_ip * nl)(*[_pi(k) for k in keep])
+        r = float(lib().orc_vcycle_hybrid(lv, nl, Rs, Ps, pp, int(nparts)))
+        self.residuals.append(r)
+        return r
 
 
 # --------------------------------------------------------------------------

@@ -97,6 +97,9 @@ def emu_lib():
         L.emu_level_bound_eval.argtypes = [C.c_void_p, _dp, _dp]
         L.emu_level_residual.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.emu_level_residual.restype = C.c_double
+        L.emu_level_sor_phases.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.emu_level_owned_sum.argtypes = [C.c_void_p, _dp]
+        L.emu_level_owned_sum.restype = C.c_double
         L.emu_level_stream_bytes.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.restype = C.c_longlong
         L.emu_level_nnz.argtypes = [C.c_void_p]
@@ -131,6 +134,12 @@ class EmuLevel:
 
     def sweeps(self, k):
         self.L.emu_level_sweeps(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp), self.omega, int(k))
+
+    def sor_phases(self):
+        self.L.emu_level_sor_phases(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp), self.omega)
+
+    def owned_sum(self):
+        return float(self.L.emu_level_owned_sum(self.h, self.x.ctypes.data_as(_dp)))
 
     def bound_eval(self):
         self.L.emu_level_bound_eval(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp))

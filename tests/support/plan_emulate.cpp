@@ -172,7 +172,7 @@ void emu_level_sweeps(void *h, double *x, const double *b, double omega, int nsw
         if (e->neumann) {
             double S = 0.0;
             for (int i = 0; i < e->n; ++i)
-                if (e->flags[i] != 2) S += x[i];
+                if (e->flags[i] < 2) S += x[i];
             double xi = b[e->n] - S;
             xi *= omega / 1.0;
             xi += (1.0 - omega) * x[e->n];
@@ -180,6 +180,23 @@ void emu_level_sweeps(void *h, double *x, const double *b, double omega, int nsw
         }
         emu_level_bound_eval(h, x, b);
     }
+}
+
+// pieces of a sweep for the distributed emulation (the multiplier update and the ghost
+// refreshes in between are done by the test)
+void emu_level_sor_phases(void *h, double *x, const double *b, double omega)
+{
+    Emu *e = static_cast<Emu *>(h);
+    const double lam = e->neumann ? x[e->n] : 0.0;
+    run_plan(e->A, M_SOR, x, nullptr, nullptr, b, omega, lam, (size_t)e->a_size, nullptr);
+}
+double emu_level_owned_sum(void *h, const double *x)
+{
+    Emu *e = static_cast<Emu *>(h);
+    double S = 0.0;
+    for (int i = 0; i < e->n; ++i)
+        if (e->flags[i] < 2) S += x[i];
+    return S;
 }
 
 double emu_level_residual(void *h, const double *x, const double *b, double *r)
@@ -194,7 +211,7 @@ double emu_level_residual(void *h, const double *x, const double *b, double *r)
     if (e->neumann) {
         double S = 0.0;
         for (int i = 0; i < e->n; ++i)
-            if (e->flags[i] != 2) S += x[i];
+            if (e->flags[i] < 2) S += x[i];
         r[e->n] = b[e->n] - (S + x[e->n]);
         nrm += std::fabs(r[e->n]);
     }
