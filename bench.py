@@ -186,8 +186,8 @@ def main():
         total_points = float(interior)
 
     # dominant kernel: per-launch HIP events on the library's stream
-    kern_ms, launches = lv.time_phases(max(2, min(a.steps, 10)))
-    sweeps_timed = max(2, min(a.steps, 10))
+    sweeps_timed = max(2, min(a.steps, 16))
+    kern_ms, launches = lv.time_phases(sweeps_timed)
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
@@ -212,7 +212,7 @@ def main():
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
                 "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
-                "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches == sweeps_timed),
+                "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches <= sweeps_timed), "sweeps_executed": a.warmup + a.steps + sweeps_timed + 2 * a.verify,
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if not dd else
                                f"domain decomposition: {world} x-slabs, RCCL ghost exchange once per sweep "
@@ -222,9 +222,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "sweep_persistent_kernel<L,MAXP>" if launches == sweeps_timed else "tile_kernel<L,MODE_SOR,MAXP>",
-                "launches": launches,
-                "avg_launch_us": kern_ms * 1e3 / launches,
+                "kernel": "sweep_persistent_kernel<L,MAXP>" if launches <= sweeps_timed else "tile_kernel<L,MODE_SOR,MAXP>",
+                "launches": launches, "sweeps_in_launches": sweeps_timed,
+                "avg_launch_us": kern_ms * 1e3 / launches, "us_per_sweep": kern_ms * 1e3 / sweeps_timed,
                 "algorithmic_bytes_per_row": b_sor(stencil),
             },
         }

@@ -145,14 +145,13 @@ int mmg_level_modify_coeff_neumann(mmg_level *lv, int coarse);
 /* values_->setZero()  multigrid.cpp:76,93 */
 int mmg_level_zero_x(mmg_level *lv);
 /* hipEvent-timed relaxation sweeps on the handle's stream: `reps` timed calls of
- * `nsweeps` sweeps; ms_out[reps] receives each call's device time.  If
- * phase_ms_sum is non-NULL it receives the summed duration of the sweep-phase
- * kernels only (measured with per-launch events in a second pass). */
+ * `nsweeps` sweeps; ms_out[reps] receives each call's device time. */
 int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out);
 int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out);
-/* nsweeps sweeps with a hipEvent pair around EVERY sweep-phase kernel launch (the
- * dominant kernel): *kernel_ms = summed durations, *launches = how many.  The
- * per-launch average must agree with rocprofv3 --kernel-trace --stats. */
+/* mmg_level_sweeps(nsweeps) with a hipEvent pair around EVERY launch of the sweep kernel (the
+ * dominant kernel; one launch may carry several fused sweeps): *kernel_ms = summed durations,
+ * *launches = how many.  kernel_ms / nsweeps must agree with rocprofv3 --kernel-trace --stats
+ * (total duration of that kernel / sweeps executed). */
 int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches);
 
 /* ---- multi-GPU: domain decomposition with RCCL ghost exchange ----------------

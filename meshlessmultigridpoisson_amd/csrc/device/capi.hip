@@ -24,6 +24,7 @@ using namespace mmg;
 namespace {
 
 thread_local std::string g_err;
+thread_local std::vector<hipEvent_t> *g_sweep_events = nullptr;  // mmg_level_time_phases: event pair per sweep-kernel launch
 bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created afterwards use the exact kernels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
 thread_local hipStream_t g_stream = nullptr;
@@ -139,7 +140,7 @@ struct PlanGpu {
     DevBuf<uint32_t> ghead;
     DevBuf<uint8_t> stream;
     DevBuf<int32_t> phase_tiles;
-    DevBuf<int32_t> dep_ptr, dep_idx;
+    DevBuf<int32_t> dep_ptr, dep_idx, later_ptr, later_idx;
     std::vector<int32_t> phase_ptr;
     PlanDev dev;
     int n_tiles = 0;
@@ -158,8 +159,12 @@ struct PlanGpu {
         HIPC(phase_tiles.upload(P.phase_tiles.data(), P.phase_tiles.size()));
         HIPC(dep_ptr.upload(P.dep_ptr.data(), P.dep_ptr.size()));
         HIPC(dep_idx.upload(P.dep_idx.data(), P.dep_idx.size()));
+        HIPC(later_ptr.upload(P.later_ptr.data(), P.later_ptr.size()));
+        HIPC(later_idx.upload(P.later_idx.data(), P.later_idx.size()));
         dev.dep_ptr = dep_ptr.p;
         dev.dep_idx = dep_idx.p;
+        dev.later_ptr = later_ptr.p;
+        dev.later_idx = later_idx.p;
         phase_ptr = P.phase_ptr;
         n_tiles = P.n_tiles;
         n_rows = P.n_rows;
@@ -301,8 +306,21 @@ int allreduce_sum(double *p, int count)
     return MMG_OK;
 }
 
-int sweep_once(mmg_level *lv)
+// `k` relaxation passes.  Returns through *done how many were performed (k when the level
+// allows fusing sweeps into one launch: nothing has to happen between two sweeps).
+int mark_event()
 {
+    if (!g_sweep_events) return MMG_OK;
+    hipEvent_t e;
+    HIPC(hipEventCreate(&e));
+    HIPC(hipEventRecord(e, g_stream));
+    g_sweep_events->push_back(e);
+    return MMG_OK;
+}
+
+int sweep_some(mmg_level *lv, int k, int *done)
+{
+    int erc;
     TileArgs a{};
     a.p = lv->A.dev;
     a.in = lv->x.p;
@@ -319,15 +337,27 @@ int sweep_once(mmg_level *lv)
         a.ticket = lv->sync_words.p;
         a.error = lv->sync_words.p + 1;
         a.done = lv->sync_words.p + 2;
-        a.epoch = ++lv->epoch;
+        // several sweeps per launch when nothing sits between them (no multiplier row, no Neumann
+        // boundary solve, no ghost exchange): the queue simply runs over sweeps x tiles
+        const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
+        const int ns = fusable ? std::min(k, 16) : 1;
+        a.epoch = lv->epoch + 1;
+        a.n_sweeps = ns;
+        lv->epoch += (unsigned)ns;
         a.fence = g_persistent_sweep == 2;
         HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
+        if ((erc = mark_event())) return erc;
         HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
+        if ((erc = mark_event())) return erc;
+        *done = ns;
     } else {
+        *done = 1;
         for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
             a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
             a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+            if ((erc = mark_event())) return erc;
             HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
+            if ((erc = mark_event())) return erc;
         }
     }
     if (lv->neumann) {
@@ -374,13 +404,15 @@ int bound_eval(mmg_level *lv)
 
 int sweeps(mmg_level *lv, int k)
 {
-    for (int it = 0; it < k; ++it) {
+    for (int it = 0; it < k;) {
         int rc = exchange(lv);
         if (rc) return rc;
-        rc = sweep_once(lv);
+        int done = 1;
+        rc = sweep_some(lv, k - it, &done);
         if (rc) return rc;
         rc = bound_eval(lv);
         if (rc) return rc;
+        it += done;
     }
     return MMG_OK;
 }
@@ -882,62 +914,24 @@ int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
 int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *launches)
 {
     if (!lv || !kernel_ms || !launches || nsweeps < 1) return fail(MMG_ERR_INVALID, "bad argument");
-    const bool persist = use_single_launch(lv);
-    const int nph = persist ? 1 : lv->A.n_phases();
-    const int total = nph * nsweeps;
-    std::vector<hipEvent_t> ev((size_t)total * 2);
-    for (auto &e : ev) HIPC(hipEventCreate(&e));
-    TileArgs a{};
-    a.p = lv->A.dev;
-    a.in = lv->x.p;
-    a.out = lv->x.p;
-    a.b = lv->b.p;
-    a.omega = lv->omega;
-    a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
-    a.flags8 = lv->flags8.p;
-    a.partial = lv->neumann ? lv->partX.p : nullptr;
-    int k = 0;
-    for (int it = 0; it < nsweeps; ++it) {
-        int rc = exchange(lv);
-        if (rc) return rc;
-        if (persist) {
-            a.tile_list = lv->A.dev.phase_tiles;
-            a.n_list = lv->A.n_tiles;
-            a.ticket = lv->sync_words.p;
-            a.error = lv->sync_words.p + 1;
-            a.done = lv->sync_words.p + 2;
-            a.epoch = ++lv->epoch;
-            a.fence = g_persistent_sweep == 2;
-            HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
-            HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
-            HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
-            HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
-            ++k;
-        } else {
-            for (int ph = 0; ph < nph; ++ph) {
-                a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
-                a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
-                HIPC(hipEventRecord(ev[(size_t)2 * k], g_stream));
-                HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
-                HIPC(hipEventRecord(ev[(size_t)2 * k + 1], g_stream));
-                ++k;
-            }
-        }
-        if (lv->neumann)
-            HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
-        rc = bound_eval(lv);
-        if (rc) return rc;
+    std::vector<hipEvent_t> ev;
+    g_sweep_events = &ev;
+    int rc = sweeps(lv, nsweeps);  // exactly what mmg_level_sweeps launches, with an event pair per sweep kernel
+    g_sweep_events = nullptr;
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(g_stream);
+        if (e != hipSuccess) rc = fail(MMG_ERR_HIP, hipGetErrorString(e));
     }
-    HIPC(hipStreamSynchronize(g_stream));
     double sum = 0.0;
-    for (int i = 0; i < total; ++i) {
+    for (size_t i = 0; i + 1 < ev.size() && !rc; i += 2) {
         float ms = 0.f;
-        HIPC(hipEventElapsedTime(&ms, ev[(size_t)2 * i], ev[(size_t)2 * i + 1]));
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) rc = fail(MMG_ERR_HIP, "hipEventElapsedTime");
         sum += ms;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
+    if (rc) return rc;
     *kernel_ms = (float)sum;
-    *launches = total;
+    *launches = (int)(ev.size() / 2);
     return check_sync_error(lv);
 }
 

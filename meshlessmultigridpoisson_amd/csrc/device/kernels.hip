@@ -305,19 +305,31 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
     const int lane = threadIdx.x;
     double lam = 0.0;
     if (a.lambda) lam = *a.lambda;
+    const unsigned total = (unsigned)a.n_list * (unsigned)a.n_sweeps;
     for (;;) {
-        unsigned q = 0;
-        if (lane == 0) q = atomicAdd(a.ticket, 1u);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= (unsigned)a.n_list) break;
+        unsigned tk = 0;
+        if (lane == 0) tk = atomicAdd(a.ticket, 1u);
+        tk = __builtin_amdgcn_readfirstlane(tk);
+        if (tk >= total) break;
+        // tickets enumerate (sweep, position in phase order); every wait below is for a smaller ticket
+        const unsigned sw = tk / (unsigned)a.n_list, q = tk - sw * (unsigned)a.n_list;
         const int tile = a.tile_list[q];
+        const unsigned want_now = a.epoch + sw;       // earlier coupled tiles: this sweep done
+        const unsigned want_prev = a.epoch + sw - 1;  // later coupled tiles: previous sweep done
         const int d0 = a.p.dep_ptr[tile], d1 = a.p.dep_ptr[tile + 1];
-        for (int base = d0; base < d1; base += 64) {
+        const int l0 = a.p.later_ptr[tile], l1 = sw > 0 ? a.p.later_ptr[tile + 1] : a.p.later_ptr[tile];
+        const int n_wait = (d1 - d0) + (l1 - l0);
+        for (int base = 0; base < n_wait; base += 64) {
             const int k = base + lane;
-            const unsigned *flag = a.done + (k < d1 ? a.p.dep_idx[k] : tile);
-            bool ok = !(k < d1);
+            const bool mine = k < n_wait;
+            const bool early = k < (d1 - d0);
+            const int dep = !mine ? tile : (early ? a.p.dep_idx[d0 + k] : a.p.later_idx[l0 + (k - (d1 - d0))]);
+            const unsigned need = early ? want_now : want_prev;
+            const unsigned *flag = a.done + dep;
+            bool ok = !mine;
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+                // flags only grow; unsigned difference handles wrap-around
+                if (!ok) ok = (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (lane == 0) __hip_atomic_store(a.done + tile, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();  // LDS of this tile is dead before the next one is staged
     }
 }

@@ -18,6 +18,8 @@ struct PlanDev {
     int max_plen = 0;
     const int32_t *dep_ptr = nullptr;  // in-place plans
     const int32_t *dep_idx = nullptr;
+    const int32_t *later_ptr = nullptr;
+    const int32_t *later_idx = nullptr;
 };
 
 enum TileMode {
@@ -43,7 +45,8 @@ struct TileArgs {
     // dependency-driven single-launch sweep (launch_sweep_persistent)
     unsigned *ticket;          // work-queue head, zeroed before the launch
     unsigned *done;            // per tile: epoch of the last completed sweep
-    unsigned epoch;
+    unsigned epoch;            // value a tile publishes after its FIRST sweep of this launch
+    int n_sweeps;              // sweeps fused into this launch (tickets run over n_sweeps * n_list)
     unsigned *error;           // set when a dependency wait times out
     int fence;                 // 1: add agent-scope acquire/release fences around every tile
 };

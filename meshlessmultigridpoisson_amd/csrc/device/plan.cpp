@@ -321,6 +321,16 @@ std::string build_plan(const PlanSpec &s, Plan *out)
                 else if (u > t) dep[u].push_back(t);
             }
         }
+        std::vector<std::vector<int32_t>> later(s.n_tiles);
+        for (int t = 0; t < s.n_tiles; ++t)
+            for (int32_t u : dep[t]) later[u].push_back(t);
+        P.later_ptr.assign((size_t)s.n_tiles + 1, 0);
+        for (int t = 0; t < s.n_tiles; ++t) {
+            std::sort(later[t].begin(), later[t].end());
+            later[t].erase(std::unique(later[t].begin(), later[t].end()), later[t].end());
+            P.later_idx.insert(P.later_idx.end(), later[t].begin(), later[t].end());
+            P.later_ptr[(size_t)t + 1] = (int32_t)P.later_idx.size();
+        }
         P.dep_ptr.assign((size_t)s.n_tiles + 1, 0);
         for (int t = 0; t < s.n_tiles; ++t) {
             int ph = 0;

@@ -83,6 +83,9 @@ struct Plan {
     // in-place plans: dep_idx[dep_ptr[t]..dep_ptr[t+1]) = earlier tiles coupled to tile t
     // (the dependency-driven single-launch sweep waits for exactly these)
     std::vector<int32_t> dep_ptr, dep_idx;
+    // later tiles coupled to tile t: they must have finished the PREVIOUS sweep before t starts the
+    // next one (several sweeps fused into one launch)
+    std::vector<int32_t> later_ptr, later_idx;
     int max_slots = 0;                 // max over tiles of n_own + n_halo + 1
     int max_groups = 0;                // max groups of one tile
     int max_own = 0;                   // max own range of one tile (b is staged next to x)

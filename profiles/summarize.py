@@ -54,14 +54,18 @@ def main():
     if bench:
         rl = bench["roofline"]
         cfg = bench["config"]
-        per_sweep = 1 if cfg.get("persistent_sweep") else cfg["phases_per_sweep"]
-        rows_per_launch = cfg["interior_points_per_gpu"] / per_sweep
-        alg = rows_per_launch * rl["algorithmic_bytes_per_row"] / 1e6
+        alg_sweep = cfg["interior_points_per_gpu"] * rl["algorithmic_bytes_per_row"] / 1e6
         lines += ["", f"bench line: {bench['value']:.0f} {bench['unit']}, {bench['ms_per_step']:.3f} ms/sweep, "
                       f"roofline {rl['achieved']:.0f} GB/s = {rl['frac']*100:.1f} % of {rl['peak']:.0f} GB/s; "
-                      f"HIP-event avg launch {rl['avg_launch_us']:.1f} us",
-                  f"algorithmic bytes per sweep-phase launch: {alg:.1f} MB; PMC traffic {traffic:.1f} MB "
-                  f"(ratio {traffic/alg:.2f})" if traffic else ""]
+                      f"HIP events: {rl.get('us_per_sweep', rl['avg_launch_us']):.1f} us per sweep "
+                      f"({rl['launches']} launches carrying {rl.get('sweeps_in_launches', rl['launches'])} sweeps)"]
+        sweep_rows = [r for r in rows if "sweep_persistent" in r["Name"] or "tile_kernel" in r["Name"]]
+        if sweep_rows and cfg.get("sweeps_executed"):
+            tot = sum(float(r["TotalDurationNs"]) for r in sweep_rows if "sweep_persistent" in r["Name"] or ", 0," in r["Name"])
+            lines.append(f"rocprofv3: sweep kernels total {tot/1e6:.2f} ms over the sweeps of the profiled run")
+        if traffic:
+            lines.append(f"algorithmic bytes per sweep: {alg_sweep:.1f} MB; PMC traffic is per LAUNCH (see table) -- divide by "
+                         f"the sweeps a launch carries")
     open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
