@@ -64,8 +64,9 @@ def main():
             tot = sum(float(r["TotalDurationNs"]) for r in sweep_rows if "sweep_persistent" in r["Name"] or ", 0," in r["Name"])
             lines.append(f"rocprofv3: sweep kernels total {tot/1e6:.2f} ms over the sweeps of the profiled run")
         if traffic:
-            lines.append(f"algorithmic bytes per sweep: {alg_sweep:.1f} MB; PMC traffic is per LAUNCH (see table) -- divide by "
-                         f"the sweeps a launch carries")
+            spl = rl.get("sweeps_in_launches", rl["launches"]) / rl["launches"]
+            lines.append(f"algorithmic bytes per sweep: {alg_sweep:.1f} MB; PMC traffic {traffic:.1f} MB per launch of "
+                         f"{spl:.0f} sweeps = {traffic/spl:.1f} MB per sweep (ratio {traffic/spl/alg_sweep:.2f})")
     open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
