@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=3)
     ap.add_argument("--polydeg", type=int, default=3)
     ap.add_argument("--tile", type=int, default=0, help="points per tile (0 = mmg_auto_tile_points)")
-    ap.add_argument("--lanes", type=int, default=2, help="lanes per row of the sweep kernel")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per row of the sweep kernel (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--persistent", type=int, default=1,

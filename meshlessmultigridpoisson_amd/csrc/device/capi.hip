@@ -703,7 +703,10 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     if (d->nb < 0 || (d->nb > 0 && (!d->btype || !d->bptr || !d->bpts || !d->bvals)))
         return fail(MMG_ERR_INVALID, "level_create: boundary arrays missing");
     const int n = d->n;
-    const int L = pick_L(d->lanes_per_row);
+    // lanes per row: long rows (3-D K = 50) stream best with 2 lanes (32 rows per group, 528 B/row
+    // packed); shorter rows keep 4 lanes so that a dependency level still fills a group
+    const int L = d->lanes_per_row > 0 ? d->lanes_per_row
+                                       : ((double)d->rowptr[d->n] / std::max(1, d->n) >= 44.0 ? 2 : 4);
     auto lv = std::make_unique<mmg_level>();
     lv->n = n;
     lv->a_size = d->a_size;
