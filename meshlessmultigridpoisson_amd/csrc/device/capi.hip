@@ -664,7 +664,7 @@ int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per
         compute_units = 256;       // MI355X
         lds_bytes_per_cu = 163840;
     }
-    const int L = lanes_per_row > 0 ? lanes_per_row : 4;
+    const int L = lanes_per_row > 0 ? lanes_per_row : (stencil >= 44 ? 2 : 4);  // as mmg_level_create picks it
     const int wave_cap = L <= 2 ? 8 : 16;  // register-limited wavefronts per CU of the sweep kernel
     // stencil reach in point spacings, fitted to the staged-halo counts of kNN stencils
     const double reach = (dim >= 3 ? 1.8 * std::cbrt(stencil / 50.0) : 2.4 * std::sqrt(stencil / 37.0));
@@ -689,6 +689,22 @@ int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per
         }
     }
     if (!best) best = best_multi;
+    // Levels far larger than the device run as one dependency-driven launch
+    // (sweep_persistent_kernel): residency rounds do not matter there, larger tiles stage fewer
+    // halo values and wait on fewer neighbours, until fewer than 6 wavefronts fit a CU.
+    // Measured at 216^3, K = 50, L = 2 (same box): T 640 -> 72.9 %, 800 -> 78.5 %, 1000 -> 76.3 %,
+    // 1280 -> 72.9 % of 8 TB/s; 736 / 832 / 896 / 928 -> 67.6 / 68.6 / 69.8 / 69.0 % on a slower box.
+    if (L <= 2) {
+        int big = 0;
+        for (int t = 256; t <= 2048; t += 32) {
+            const double side = dim >= 3 ? std::cbrt((double)t) : std::sqrt((double)t);
+            const double halo = std::pow(side + 2 * reach, dim >= 3 ? 3.0 : 2.0) - t;
+            const double lds = (2.0 * t + halo + 1) * 8 + 256;
+            if (lds * 6 > 0.97 * lds_bytes_per_cu) break;
+            big = t;
+        }
+        if (big > best && (double)n_points / big >= 2.0 * 6 * compute_units) best = big;
+    }
     return best;
 }
 
