@@ -65,5 +65,8 @@ def test_host_library_loads_and_links_capi():
 
 def test_auto_tile_points_is_device_free_arithmetic():
     from meshlessmultigridpoisson_amd import _capi
-    assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 640  # one residency round per phase
+    # device-filling level: largest tile that keeps 6 wavefronts per CU (single dependency-driven launch)
+    assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 896
+    assert _capi.auto_tile_points(10077696, 3, 50, 0, 256, 163840) == 896  # lanes 0: as mmg_level_create picks L
+    assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 256  # one residency round per phase
     assert _capi.auto_tile_points(10000, 2, 37, 4, 256, 163840) == 256
