@@ -7,9 +7,11 @@ in the storage (Gauss-Seidel) order, by the hand-written gfx950 sweep kernel.
 
 Workload at N=1: BASELINE.json configs[2] -- 3-D unit cube, 216^3 = 1.008e7 points,
 K = 50 neighbours per stencil (3-D polyDeg 3), fp64, Dirichlet, multicolour tile
-ordering; the operator is the synthetic kNN-graph Laplacian on exactly that sparsity
-(Grid::build_graph_laplacian): same bytes per row as the RBF-FD Laplacian, values
-do not influence throughput.  All inputs are resident in HBM before the timed region.
+ordering; the operator is the RBF-FD Laplacian of the reference (Grid::build_laplacian:
+PHS r^3 + degree-3 polynomials, one 70 x 70 full-pivot LU per point, batched on the GPU
+by mmg_rbf_weights during the untimed setup).  --operator graph selects the synthetic
+kNN-graph Laplacian on the same sparsity instead (same bytes per row).  All inputs are
+resident in HBM before the timed region.
 
 N>1 (one process per GPU, torch.distributed/RCCL): weak scaling, every rank owns one
 such sub-domain of an N-times larger cloud; see DESIGN.md "Multi-GPU".
@@ -46,6 +48,8 @@ def parse():
     ap.add_argument("--polydeg", type=int, default=3)
     ap.add_argument("--tile", type=int, default=0, help="points per tile (0 = mmg_auto_tile_points)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per row of the sweep kernel (0 = library default)")
+    ap.add_argument("--operator", choices=("rbf", "graph"), default="rbf",
+                    help="rbf: the reference's RBF-FD Laplacian (device-batched setup); graph: kNN-graph Laplacian")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--persistent", type=int, default=1,
@@ -111,16 +115,20 @@ def main():
     if a.tile <= 0:
         a.tile = _capi.auto_tile_points(a.nside ** a.dim, a.dim, stencil, a.lanes, cus, lds)
     dd = world > 1 or a.force_dd
+    kind = _host.KIND_DIRICHLET if a.operator == "rbf" else _host.KIND_GRAPH
+    if a.operator == "rbf":
+        _host.set_option("device_setup", 1)   # the 70 x 70 saddle systems of 1e7 stencils: seconds on the GPU
     if not dd:
         pts = _host.box_cloud(a.nside, a.dim, seed=12345)
-        grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC,
+        grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=kind, ordering=_host.ORDER_MC,
                                         tile_points=a.tile, lanes_per_row=a.lanes)
         n_owned = grid.sizes()["n"]
     else:
         # domain decomposition: rank r owns x-layers [r*nside, (r+1)*nside) of a (world*nside) x nside^(dim-1)
         # lattice and builds ONLY its own rows; ghost ids are agreed on with one all_gather at setup
         pts, flags, gid, owner = _host.slab_cloud(rank, world, a.nside, dim=a.dim, margin=5)
-        grid = _host.Grid.create_local(pts, flags, gid, owner, a.dim, stencil, tile_points=a.tile, lanes_per_row=a.lanes)
+        grid = _host.Grid.create_local(pts, flags, gid, owner, a.dim, stencil, tile_points=a.tile, lanes_per_row=a.lanes,
+                                       kind=kind, polydeg=a.polydeg)
         n_owned, lgid, gown = grid.local_map()
 
         def all_gather_object(obj):
@@ -207,7 +215,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{a.dim}-D {a.nside}^{a.dim} = {n_owned} points per GPU, K={stencil} "
-                            f"kNN stencils (graph-Laplacian values on the RBF-FD sparsity), Dirichlet, "
+                            f"kNN stencils ({'RBF-FD Laplacian, PHS r^3 + degree-' + str(a.polydeg) + ' polynomials' if a.operator == 'rbf' else 'graph-Laplacian values on the RBF-FD sparsity'}), Dirichlet, "
                             f"one SOR sweep per step (BASELINE configs[2])",
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
                 "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],

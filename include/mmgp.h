@@ -213,6 +213,21 @@ void mmg_spmv_destroy(mmg_spmv *m);
 /* y = A x on host vectors (uploads x, downloads y) */
 int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny);
 
+/* ---- setup: batched RBF-FD stencil weights ---------------------------------------------------
+ * Replaces the per-point dense solves of the reference's setup: Grid::buildCoeffMatrix
+ * (grid.cpp:263-303) + fullPivLu().solve in laplaceWeights (:381-424), derivx/derivy_weights
+ * (:304-380), pointInterpWeights (:687-712), with shifting_scaling
+ * (general_computation_functions.cpp:82-134) applied to every stencil.
+ *   cloud_xyz [n_cloud][3]  coordinates (z ignored when dim == 2)
+ *   eval_xyz  [n_eval][3]   evaluation point of each stencil
+ *   nbr       [n_eval][stencil]  neighbour ids into cloud_xyz, nearest first (kNearestNeighbors)
+ *   ops       [n_ops]       0 laplace, 1 d/dx, 2 d/dy, 3 d/dz, 4 interpolation (<= 4 per call,
+ *                           solved against ONE factorisation)
+ *   weights   [n_ops][n_eval][stencil]  out: the first `stencil` solution entries */
+int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                    long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
+                    double *weights);
+
 /* ---- fractional-step grid == FractionalStepGrid (fractionalStepGrid.hpp) -------------------
  * Velocity predictor, pressure-Poisson source and corrector around the pressure level `p`
  * (whose values_/source_ are the pressure and the PPE right-hand side).  u, v, u_hat, v_hat

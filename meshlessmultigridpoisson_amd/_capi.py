@@ -46,7 +46,7 @@ SYMBOLS = [
     "mmg_level_residual_ratio", "mmg_level_boundary_op", "mmg_level_modify_coeff_neumann", "mmg_level_zero_x",
     "mmg_level_time_sweeps", "mmg_level_time_residual", "mmg_level_time_phases", "mmg_transfer_create", "mmg_transfer_destroy",
     "mmg_restrict", "mmg_prolong_add", "mmg_hierarchy_create", "mmg_hierarchy_destroy", "mmg_vcycle",
-    "mmg_hierarchy_residual", "mmg_vcycles", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply", "mmg_fracstep_create", "mmg_fracstep_destroy",
+    "mmg_hierarchy_residual", "mmg_vcycles", "mmg_rbf_weights", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply", "mmg_fracstep_create", "mmg_fracstep_destroy",
     "mmg_fracstep_set", "mmg_fracstep_get", "mmg_fracstep_calc_hat", "mmg_fracstep_set_ppe_source",
     "mmg_fracstep_correct", "mmg_fracstep_residual",
 ]
@@ -155,6 +155,21 @@ def device_props():
     cu, lds = C.c_int(0), C.c_int(0)
     check(lib().mmg_device_props(C.byref(cu), C.byref(lds)))
     return cu.value, lds.value
+
+
+def rbf_weights(dim, polydeg, rbf_exp, cloud_xyz, eval_xyz, nbr, ops):
+    """mmg_rbf_weights: batched RBF-FD stencil weights; returns [n_ops][n_eval][stencil]."""
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float64).reshape(-1, 3)
+    ev = np.ascontiguousarray(eval_xyz, dtype=np.float64).reshape(-1, 3)
+    nb = np.ascontiguousarray(nbr, dtype=np.int32)
+    assert nb.ndim == 2 and nb.shape[0] == ev.shape[0]
+    op = np.ascontiguousarray(ops, dtype=np.int32)
+    out = np.zeros((len(op), ev.shape[0], nb.shape[1]))
+    f = lib().mmg_rbf_weights
+    f.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _dp, C.c_longlong, _dp, _ip, C.c_int, _ip, _dp]
+    check(f(dim, polydeg, float(rbf_exp), nb.shape[1], cloud.shape[0], cloud.ctypes.data_as(_dp), ev.shape[0],
+            ev.ctypes.data_as(_dp), nb.ctypes.data_as(_ip), len(op), op.ctypes.data_as(_ip), out.ctypes.data_as(_dp)))
+    return out
 
 
 def device_count():

@@ -97,9 +97,16 @@ def lib():
         L.mmgh_grid_local_map.argtypes = [vp, _ip, _ip]
         L.mmgh_grid_create_local.restype = vp
         L.mmgh_grid_create_local.argtypes = [C.c_int, _dp, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
-                                             C.c_double, C.c_int]
+                                             C.c_double, C.c_int, C.c_int, C.c_int]
+        L.mmgh_set_option.argtypes = [C.c_char_p, C.c_int]
         _lib = L
     return _lib
+
+
+def set_option(name, value):
+    """mmgh_set_option: "device_setup" -1 automatic / 0 host threads / 1 batched dense solves on the MI355X."""
+    if lib().mmgh_set_option(name.encode(), int(value)) != 0:
+        raise HostError(_err())
 
 
 def stencil_size(polydeg, dim=2):
@@ -165,11 +172,12 @@ class Grid:
         return g
 
     @classmethod
-    def create_local(cls, points, flags, gid, owner, dim, stencil, tile_points=0, lanes_per_row=0, omega=1.4, iters=5):
+    def create_local(cls, points, flags, gid, owner, dim, stencil, tile_points=0, lanes_per_row=0, omega=1.4, iters=5,
+                     kind=KIND_GRAPH, polydeg=3):
         pts, flags, gid, owner = _d(points).reshape(-1, 3), _i(flags), _i(gid), _i(owner)
         h = lib().mmgh_grid_create_local(len(pts), pts.ctypes.data_as(_dp), flags.ctypes.data_as(_ip),
                                          gid.ctypes.data_as(_ip), owner.ctypes.data_as(_ip), dim, stencil, tile_points,
-                                         lanes_per_row, omega, iters)
+                                         lanes_per_row, omega, iters, kind, polydeg)
         if not h:
             raise HostError(_err())
         g = cls(h)

@@ -13,6 +13,7 @@
 
 #include "../../../include/mmgp.h"
 #include "kernels.hpp"
+#include "rbf_setup.hpp"
 #include "level_plan.hpp"
 #include "plan.hpp"
 
@@ -1164,6 +1165,63 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny)
     HIPC(run_tiles(m->plan, MODE_SET, a, g_stream));
     HIPC(hipMemcpyAsync(y, m->y.p, sizeof(double) * (size_t)ny, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
+    return MMG_OK;
+}
+
+// ---- setup: batched RBF-FD stencil weights (rbf_setup.hip) ------------------------------
+int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                    long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
+                    double *weights)
+{
+    if (dim < 2 || dim > 3 || poly_deg < 0 || poly_deg > 8 || stencil < 1 || n_cloud < 1 || n_eval < 0 || !cloud_xyz ||
+        !eval_xyz || !nbr || n_ops < 1 || n_ops > 4 || !ops || !weights)
+        return fail(MMG_ERR_INVALID, "rbf_weights: bad argument");
+    const int pt = dim >= 3 ? (poly_deg + 1) * (poly_deg + 2) * (poly_deg + 3) / 6 : (poly_deg + 1) * (poly_deg + 2) / 2;
+    if (2 * stencil < pt) return fail(MMG_ERR_INVALID, "rbf_weights: stencil smaller than half the polynomial terms");
+    for (int o = 0; o < n_ops; ++o)
+        if (ops[o] < 0 || ops[o] > 4 || (ops[o] == RBF_OP_DZ && dim < 3)) return fail(MMG_ERR_INVALID, "rbf_weights: bad operator id");
+    // every neighbour id is dereferenced on the device: check them here, on the host
+    for (long long i = 0; i < n_eval * stencil; ++i)
+        if (nbr[i] < 0 || nbr[i] >= n_cloud) return fail(MMG_ERR_INVALID, "rbf_weights: neighbour id out of range");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_eval == 0) return MMG_OK;
+    RbfArgs a{};
+    const size_t lds = rbf_lds_bytes(stencil, pt, n_ops, &a.ld);
+    int cus = 0, lds_cu = 0;
+    if ((rc = mmg_device_props(&cus, &lds_cu))) return rc;
+    if (lds > (size_t)lds_cu) return fail(MMG_ERR_UNSUPPORTED, "rbf_weights: saddle system does not fit the LDS of one CU");
+    DevBuf<double> d_cloud, d_eval, d_w;
+    DevBuf<int> d_nbr;
+    HIPC(d_cloud.upload(cloud_xyz, (size_t)n_cloud * 3));
+    // evaluation points in chunks: bounds the device footprint (nbr + weights: 12 B x stencil x n_ops per point)
+    const long long chunk = 1 << 21;
+    HIPC(d_eval.alloc((size_t)std::min(n_eval, chunk) * 3));
+    HIPC(d_nbr.alloc((size_t)std::min(n_eval, chunk) * stencil));
+    HIPC(d_w.alloc((size_t)std::min(n_eval, chunk) * stencil * n_ops));
+    const int resident = std::max(1, cus * std::max(1, (int)((size_t)lds_cu / lds)));
+    for (long long e0 = 0; e0 < n_eval; e0 += chunk) {
+        const long long ne = std::min(chunk, n_eval - e0);
+        HIPC(hipMemcpyAsync(d_eval.p, eval_xyz + 3 * e0, sizeof(double) * 3 * (size_t)ne, hipMemcpyHostToDevice, g_stream));
+        HIPC(hipMemcpyAsync(d_nbr.p, nbr + e0 * stencil, sizeof(int) * (size_t)ne * stencil, hipMemcpyHostToDevice, g_stream));
+        a.cloud = d_cloud.p;
+        a.eval = d_eval.p;
+        a.nbr = d_nbr.p;
+        a.w = d_w.p;
+        a.n_eval = ne;
+        a.ss = stencil;
+        a.pt = pt;
+        a.dim = dim;
+        a.poly_deg = poly_deg;
+        a.n_ops = n_ops;
+        for (int o = 0; o < n_ops; ++o) a.ops[o] = ops[o];
+        a.rbf_exp = rbf_exp;
+        HIPC(launch_rbf_weights(a, (int)std::min<long long>(ne, 2LL * resident), lds, g_stream));
+        for (int o = 0; o < n_ops; ++o)
+            HIPC(hipMemcpyAsync(weights + ((size_t)o * n_eval + e0) * stencil, d_w.p + (size_t)o * ne * stencil,
+                                sizeof(double) * (size_t)ne * stencil, hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+    }
     return MMG_OK;
 }
 

@@ -1,0 +1,280 @@
+// rbf_setup.hip -- batched RBF-FD stencil weights on gfx950 (scalable setup).
+//
+// Replaces the per-point dense solves of the reference's setup
+//   Grid::buildCoeffMatrix      grid.cpp:263-303   (PHS r^m block + polynomial block)
+//   Grid::laplaceWeights        grid.cpp:381-424
+//   Grid::derivx/derivy_weights grid.cpp:304-380
+//   Grid::pointInterpWeights    grid.cpp:687-712
+//   shifting_scaling            general_computation_functions.cpp:82-134
+// each of which ends in Eigen's fullPivLu().solve of an (ss+pt) x (ss+pt) saddle system
+// (ss = stencil size, pt = polynomial terms; 70 x 70 for the 3-D degree-3 stencils of the
+// 1e7-point configuration).  One 64-lane workgroup == one wavefront owns one stencil at a
+// time: coordinates are shifted/scaled in registers, the system is assembled column-major in
+// LDS, factorised in place with FULL pivoting (the search for the next pivot is fused into the
+// rank-1 update, ties resolved like a column-major scan: smallest column, then smallest row),
+// every requested right-hand side is solved against the one factorisation.  No inter-wave
+// synchronisation; a wavefront's LDS accesses are in order.  Compute/LDS-bound setup work,
+// not part of the timed hot path.
+#include <hip/hip_runtime.h>
+
+#include "rbf_setup.hpp"
+
+namespace mmg {
+namespace {
+
+__device__ __forceinline__ double wmax(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wmin(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ double ipow(double x, int e)
+{
+    double r = 1.0;
+    for (int k = 0; k < e; ++k) r *= x;
+    return r;
+}
+
+// pow(d, m) of the PHS kernel; m = 3 (the reference's rbfExp) avoids the generic pow
+__device__ __forceinline__ double phs(double d, double m)
+{
+    if (m == 3.0) return d * d * d;
+    if (m == 5.0) return d * d * d * d * d;
+    return d > 0.0 ? pow(d, m) : 0.0;
+}
+
+// One wavefront, one stencil at a time.  LDS layout (doubles):
+//   A[n*ld] | rhs[n_ops*n] | sx[ss] sy[ss] sz[ss] (y[n] reuses this space in the solves) |
+//   (ints) cperm[n] ea[pt] eb[pt] ec[pt]
+__global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int ss = a.ss, pt = a.pt, n = ss + pt, ld = a.ld;
+    double *A = reinterpret_cast<double *>(smem);
+    double *rhs = A + (size_t)n * ld;
+    double *sx = rhs + (size_t)a.n_ops * n;
+    double *sy = sx + ss;
+    double *sz = sy + ss;
+    double *yv = sx;  // coordinates are dead once the system and its right-hand sides exist (3 ss >= n)
+    int *cperm = reinterpret_cast<int *>(sz + ss);
+    int *ea = cperm + n;
+    int *eb = ea + pt;
+    int *ec = eb + pt;
+
+    // monomial exponents in the reference's enumeration order (grid.cpp:285-297)
+    if (lane == 0) {
+        int c = 0;
+        for (int p = 0; p <= a.poly_deg; ++p)
+            for (int q = 0; q <= p; ++q) {
+                if (a.dim < 3) {
+                    ea[c] = p - q; eb[c] = q; ec[c] = 0; ++c;
+                } else {
+                    for (int s = 0; s <= q; ++s) { ea[c] = p - q; eb[c] = q - s; ec[c] = s; ++c; }
+                }
+            }
+    }
+    __syncthreads();
+    const double M = a.rbf_exp;
+
+    for (long long e = blockIdx.x; e < a.n_eval; e += gridDim.x) {
+        // ---- shifting_scaling: bounding box of the stencil points, longest side = scale ----
+        double lox = 1e300, hix = -1e300, loy = 1e300, hiy = -1e300, loz = 1e300, hiz = -1e300;
+        for (int i = lane; i < ss; i += 64) {
+            const long long id = a.nbr[e * ss + i];
+            const double x = a.cloud[3 * id], y = a.cloud[3 * id + 1], z = a.cloud[3 * id + 2];
+            sx[i] = x; sy[i] = y; sz[i] = z;
+            lox = fmin(lox, x); hix = fmax(hix, x);
+            loy = fmin(loy, y); hiy = fmax(hiy, y);
+            loz = fmin(loz, z); hiz = fmax(hiz, z);
+        }
+        lox = wmin(lox); hix = wmax(hix); loy = wmin(loy); hiy = wmax(hiy);
+        double scale = fmax(hix - lox, hiy - loy);
+        if (a.dim >= 3) {
+            loz = wmin(loz); hiz = wmax(hiz);
+            scale = fmax(scale, hiz - loz);
+        } else {
+            loz = 0.0;
+        }
+        for (int i = lane; i < ss; i += 64) {
+            sx[i] = (sx[i] - lox) / scale;
+            sy[i] = (sy[i] - loy) / scale;
+            sz[i] = a.dim >= 3 ? (sz[i] - loz) / scale : 0.0;
+        }
+        const double xe = (a.eval[3 * e] - lox) / scale, ye = (a.eval[3 * e + 1] - loy) / scale;
+        const double ze = a.dim >= 3 ? (a.eval[3 * e + 2] - loz) / scale : 0.0;
+        __syncthreads();
+
+        // ---- assemble [Phi P; P^T 0] column-major, track the first pivot --------------------
+        double best = -1.0;
+        int bidx = 0x7fffffff;
+        for (int idx = lane; idx < n * n; idx += 64) {
+            const int j = idx / n, i = idx - j * n;
+            double v = 0.0;
+            if (i < ss && j < ss) {
+                const double dx = sx[i] - sx[j], dy = sy[i] - sy[j], dz = sz[i] - sz[j];
+                v = phs(sqrt(dx * dx + dy * dy + dz * dz), M);
+            } else if (i < ss || j < ss) {
+                const int r = i < ss ? i : j, c = (i < ss ? j : i) - ss;
+                v = ipow(sx[r], ea[c]) * ipow(sy[r], eb[c]) * ipow(sz[r], ec[c]);
+            }
+            A[(size_t)j * ld + i] = v;
+            const double av = fabs(v);
+            if (av > best) { best = av; bidx = idx; }
+        }
+        // ---- right-hand sides (grid.cpp:312-331, :351-370, :389-413, :697-707) -------------
+        for (int o = 0; o < a.n_ops; ++o) {
+            const int op = a.ops[o];
+            for (int i = lane; i < n; i += 64) {
+                double v = 0.0;
+                if (i < ss) {
+                    const double xr = sx[i], yr = sy[i], zr = sz[i];
+                    if (op == RBF_OP_LAPLACE) {
+                        double D = xe * xe - 2 * xe * xr + xr * xr + ye * ye - 2 * ye * yr + yr * yr;
+                        double g2 = (2 * xe - 2 * xr) * (2 * xe - 2 * xr) + (2 * ye - 2 * yr) * (2 * ye - 2 * yr);
+                        if (a.dim >= 3) {
+                            D += ze * ze - 2 * ze * zr + zr * zr;
+                            g2 += (2 * ze - 2 * zr) * (2 * ze - 2 * zr);
+                        }
+                        if (D > 0) v = g2 * (M / 2) * (M / 2 - 1) * pow(D, M / 2 - 2) + a.dim * M * pow(D, M / 2 - 1);
+                    } else {
+                        const double dx = xe - xr, dy = ye - yr, dz = ze - zr;
+                        const double d = sqrt(dx * dx + dy * dy + dz * dz);
+                        if (op == RBF_OP_INTERP) v = phs(d, M);
+                        else if (i > 0) {
+                            const double delta = op == RBF_OP_DX ? dx : (op == RBF_OP_DY ? dy : dz);
+                            v = M * (M == 3.0 ? d : (d > 0.0 ? pow(d, M - 2) : 0.0)) * delta;
+                        }
+                    }
+                } else {
+                    const int c = i - ss, ax = ea[c], bx = eb[c], cx = ec[c];
+                    if (op == RBF_OP_INTERP) v = ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx);
+                    else if (op == RBF_OP_DX) { if (ax >= 1) v = ax * ipow(xe, ax - 1) * ipow(ye, bx) * ipow(ze, cx); }
+                    else if (op == RBF_OP_DY) { if (bx >= 1) v = bx * ipow(xe, ax) * ipow(ye, bx - 1) * ipow(ze, cx); }
+                    else if (op == RBF_OP_DZ) { if (cx >= 1) v = cx * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 1); }
+                    else {
+                        if (ax >= 2) v += ax * (ax - 1) * ipow(xe, ax - 2) * ipow(ye, bx) * ipow(ze, cx);
+                        if (bx >= 2) v += bx * (bx - 1) * ipow(xe, ax) * ipow(ye, bx - 2) * ipow(ze, cx);
+                        if (cx >= 2) v += cx * (cx - 1) * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 2);
+                    }
+                }
+                rhs[(size_t)o * n + i] = v;
+            }
+        }
+        for (int i = lane; i < n; i += 64) cperm[i] = i;
+        __syncthreads();
+
+        // ---- full-pivot LU, in place ---------------------------------------------------------
+        int rank = n;
+        for (int k = 0; k < n; ++k) {
+            // wave argmax of (best, bidx): larger value first, then the smaller column-major index
+#pragma unroll
+            for (int msk = 32; msk >= 1; msk >>= 1) {
+                const double ob = __shfl_xor(best, msk, 64);
+                const int oi = __shfl_xor(bidx, msk, 64);
+                if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            }
+            if (!(best > 0.0)) { rank = k; break; }
+            const int m0 = n - k;                      // the search ran over the m0 x m0 trailing block
+            const int pc = k + bidx / m0, pr = k + (bidx - (bidx / m0) * m0);
+            if (pr != k) {
+                for (int j = lane; j < n; j += 64) {
+                    const double t = A[(size_t)j * ld + k];
+                    A[(size_t)j * ld + k] = A[(size_t)j * ld + pr];
+                    A[(size_t)j * ld + pr] = t;
+                }
+                if (lane < a.n_ops) {
+                    const double t = rhs[(size_t)lane * n + k];
+                    rhs[(size_t)lane * n + k] = rhs[(size_t)lane * n + pr];
+                    rhs[(size_t)lane * n + pr] = t;
+                }
+            }
+            __syncthreads();
+            if (pc != k) {
+                for (int i = lane; i < n; i += 64) {
+                    const double t = A[(size_t)k * ld + i];
+                    A[(size_t)k * ld + i] = A[(size_t)pc * ld + i];
+                    A[(size_t)pc * ld + i] = t;
+                }
+                if (lane == 0) { const int t = cperm[k]; cperm[k] = cperm[pc]; cperm[pc] = t; }
+            }
+            __syncthreads();
+            const double piv = A[(size_t)k * ld + k];
+            const int m = n - k - 1;
+            for (int i = lane; i < m; i += 64) A[(size_t)k * ld + k + 1 + i] /= piv;
+            __syncthreads();
+            // rank-1 update of the trailing m x m block + search of the next pivot
+            best = -1.0;
+            bidx = 0x7fffffff;
+            if (m > 0) {
+                const int sj = 64 / m, si = 64 - sj * m;
+                int j = lane / m, i = lane - j * m;
+                for (int idx = lane; idx < m * m; idx += 64) {
+                    double *col = A + (size_t)(k + 1 + j) * ld;
+                    const double v = col[k + 1 + i] - A[(size_t)k * ld + k + 1 + i] * col[k];
+                    col[k + 1 + i] = v;
+                    const double av = fabs(v);
+                    if (av > best) { best = av; bidx = idx; }
+                    i += si; j += sj;
+                    if (i >= m) { i -= m; ++j; }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- solves: unit-lower forward, upper backward (column sweeps), unpermute ----------
+        for (int o = 0; o < a.n_ops; ++o) {
+            double *b = rhs + (size_t)o * n;
+            for (int k = 0; k < rank; ++k) {
+                const double bk = b[k];
+                for (int i = k + 1 + lane; i < n; i += 64) b[i] -= A[(size_t)k * ld + i] * bk;
+                __syncthreads();
+            }
+            for (int i = lane; i < n; i += 64) yv[i] = 0.0;
+            __syncthreads();
+            for (int k = rank - 1; k >= 0; --k) {
+                const double yk = b[k] / A[(size_t)k * ld + k];
+                if (lane == 0) yv[k] = yk;
+                for (int i = lane; i < k; i += 64) b[i] -= A[(size_t)k * ld + i] * yk;
+                __syncthreads();
+            }
+            const int op = a.ops[o];
+            const double div = op == RBF_OP_LAPLACE ? scale * scale : (op == RBF_OP_INTERP ? 1.0 : scale);
+            // weights of the stencil points only (the polynomial multipliers are dropped by every caller)
+            for (int k = lane; k < n; k += 64) {
+                const int c = cperm[k];
+                if (c < ss) a.w[((size_t)o * a.n_eval + e) * ss + c] = yv[k] / div;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out)
+{
+    const int n = ss + pt;
+    const int ld = n;  // 70 x 70 doubles + the rest stay below 40 KiB: four workgroups per CU
+    if (ld_out) *ld_out = ld;
+    size_t d = (size_t)n * ld + (size_t)n_ops * n + 3 * (size_t)ss;
+    return d * 8 + ((size_t)n + 3 * (size_t)pt) * 4 + 16;
+}
+
+hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rbf_weights_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rbf_weights_kernel, dim3((unsigned)blocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace mmg

@@ -1,0 +1,28 @@
+// rbf_setup.hpp -- launch interface of the batched RBF-FD weight kernel (rbf_setup.hip).
+#ifndef MMG_RBF_SETUP_HPP
+#define MMG_RBF_SETUP_HPP
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace mmg {
+
+enum RbfOp { RBF_OP_LAPLACE = 0, RBF_OP_DX = 1, RBF_OP_DY = 2, RBF_OP_DZ = 3, RBF_OP_INTERP = 4 };
+
+struct RbfArgs {
+    const double *cloud;  // [n_cloud][3] coordinates the neighbour ids refer to
+    const double *eval;   // [n_eval][3] evaluation points
+    const int *nbr;       // [n_eval][ss] neighbour ids, nearest first
+    double *w;            // [n_ops][n_eval][ss] stencil weights
+    long long n_eval;
+    int ss, pt, ld, dim, poly_deg, n_ops;
+    int ops[4];
+    double rbf_exp;
+};
+
+// dynamic LDS of one workgroup; *ld_out = leading dimension of the column-major system
+size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out);
+hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s);
+
+}  // namespace mmg
+#endif

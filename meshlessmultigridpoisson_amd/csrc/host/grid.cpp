@@ -70,6 +70,7 @@ Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties pro
     residuals_ = nullptr;
     neumann_boundary_coeffs_ = new SparseRowMajor(A_size, A_size, true);
     diags = VectorXd((size_t)A_size);
+    device_setup_ = default_device_setup;
 }
 
 Grid::~Grid()
@@ -321,6 +322,47 @@ void Grid::build_deriv_normal_bound()
     });
 }
 
+int Grid::default_device_setup = -1;
+
+bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
+                            const vector<int> &ops, vector<int> &nbr, vector<double> &w)
+{
+    const long long ne = (long long)evals.size();
+    if (device_setup_ == 0 || ne == 0) return false;
+    if (device_setup_ < 0) {
+        int ndev = 0;
+        if (ne < kDeviceSetupMin || mmg_device_count(&ndev) != MMG_OK || ndev < 1) return false;
+    }
+    const int ss = stencilSizeFor(polyDeg, dim_);
+    if ((int)points_.size() < ss) return false;
+    ensure_knn();
+    nbr.assign((size_t)ne * (size_t)ss, 0);
+    std::atomic<int> short_rows{0};
+    parallel_for((int)ne, threads(), [&](int e) {
+        const bool isb = evalIsBoundary ? (*evalIsBoundary)[(size_t)e] != 0 : false;
+        const vector<int> nb = kNearestNeighbors(evals[(size_t)e], neumann, isb, ss);
+        if ((int)nb.size() != ss) { short_rows++; return; }
+        std::copy(nb.begin(), nb.end(), nbr.begin() + (size_t)e * (size_t)ss);
+    });
+    if (short_rows.load() > 0) return false;  // fewer candidates than the stencil wants: host path decides
+    std::vector<double> cloud(points_.size() * 3), ev((size_t)ne * 3);
+    for (size_t i = 0; i < points_.size(); ++i) {
+        cloud[3 * i] = std::get<0>(points_[i]);
+        cloud[3 * i + 1] = std::get<1>(points_[i]);
+        cloud[3 * i + 2] = std::get<2>(points_[i]);
+    }
+    for (size_t e = 0; e < (size_t)ne; ++e) {
+        ev[3 * e] = std::get<0>(evals[e]);
+        ev[3 * e + 1] = std::get<1>(evals[e]);
+        ev[3 * e + 2] = std::get<2>(evals[e]);
+    }
+    w.assign(ops.size() * (size_t)ne * (size_t)ss, 0.0);
+    dev_check(mmg_rbf_weights(dim_, polyDeg, (double)properties_.rbfExp, ss, (int)points_.size(), cloud.data(), ne, ev.data(),
+                              nbr.data(), (int)ops.size(), ops.data(), w.data()),
+              "mmg_rbf_weights");
+    return true;
+}
+
 // grid.cpp:549-663
 void Grid::build_laplacian()
 {
@@ -329,12 +371,69 @@ void Grid::build_laplacian()
     ensure_knn();
     std::vector<std::vector<double>> W((size_t)n);
     std::vector<vector<int>> NB((size_t)n);
-    parallel_for(n, threads(), [&](int i) {
-        if (bcFlags_[(size_t)i] == kGhost) return;  // ghost points own no row
-        auto w = laplaceWeights(i);
-        W[(size_t)i] = w.first.host();
-        NB[(size_t)i] = std::move(w.second);
-    });
+    {
+        // batched on the device when it pays (see batched_stencils); rows of ghost points do not exist
+        vector<int> ids;
+        vector<Point> ev;
+        vector<char> isb;
+        for (int i = 0; i < n; ++i)
+            if (bcFlags_[(size_t)i] != kGhost) {
+                ids.push_back(i);
+                ev.push_back(points_[(size_t)i]);
+                isb.push_back(bcFlags_[(size_t)i] != 0);
+            }
+        vector<int> nbr;
+        vector<double> w;
+        const int ss = stencilSizeFor(properties_.polyDeg, dim_);
+        if (batched_stencils(ev, &isb, neumannFlag_, properties_.polyDeg, {(int)OP_LAPLACE}, nbr, w)) {
+            vector<Point>().swap(ev);
+            if (!neumannFlag_) {
+                // Dirichlet problems: every row is its stencil -- assemble the CSR directly
+                // (same result as setFromTriplets: columns ascending, no duplicates in a kNN row)
+                std::vector<int> outer((size_t)n + 1, 0), inner(ids.size() * (size_t)ss);
+                std::vector<double> val(ids.size() * (size_t)ss);
+                {
+                    size_t k = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const bool has = k < ids.size() && ids[k] == i;
+                        outer[(size_t)i + 1] = outer[(size_t)i] + (has ? ss : 0);
+                        if (has) ++k;
+                    }
+                }
+                std::vector<double> &dg = diags.host_mut();
+                parallel_for((int)ids.size(), threads(), [&](int k) {
+                    const int i = ids[(size_t)k];
+                    std::vector<std::pair<int, double>> row((size_t)ss);
+                    for (int j = 0; j < ss; ++j) row[(size_t)j] = {nbr[(size_t)k * ss + j], w[(size_t)k * ss + j]};
+                    std::sort(row.begin(), row.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+                    const size_t base = (size_t)outer[(size_t)i];
+                    for (int j = 0; j < ss; ++j) {
+                        inner[base + j] = row[(size_t)j].first;
+                        val[base + j] = row[(size_t)j].second;
+                        if (row[(size_t)j].first == i) dg[(size_t)i] = row[(size_t)j].second;
+                    }
+                });
+                const int rows = laplaceMat_->rows();
+                delete laplaceMat_;
+                laplaceMat_ = new SparseRowMajor(rows, rows, true);
+                laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(val));
+                vector<Triplet> none;
+                neumann_boundary_coeffs_->setFromTriplets(none.begin(), none.end());
+                return;
+            }
+            for (size_t k = 0; k < ids.size(); ++k) {
+                W[(size_t)ids[k]].assign(w.begin() + (long)(k * ss), w.begin() + (long)((k + 1) * ss));
+                NB[(size_t)ids[k]].assign(nbr.begin() + (long)(k * ss), nbr.begin() + (long)((k + 1) * ss));
+            }
+        } else {
+            parallel_for(n, threads(), [&](int i) {
+                if (bcFlags_[(size_t)i] == kGhost) return;  // ghost points own no row
+                auto w1 = laplaceWeights(i);
+                W[(size_t)i] = w1.first.host();
+                NB[(size_t)i] = std::move(w1.second);
+            });
+        }
+    }
     vector<Triplet> trip, btrip;
     trip.reserve((size_t)n * (size_t)(properties_.stencilSize + 2));
     for (int i = 0; i < n; ++i) {

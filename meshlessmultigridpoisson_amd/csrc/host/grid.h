@@ -57,6 +57,12 @@ public:
     int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy
     int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
     int setup_threads_ = 0;      // 0 = hardware concurrency
+    // Dense stencil solves of the setup (laplaceWeights / pointInterpWeights / deriv*_weights):
+    // -1 automatic (batched on the MI355X through mmg_rbf_weights when a device is present and
+    // at least kDeviceSetupMin stencils are wanted), 0 host threads, 1 device.
+    int device_setup_ = -1;
+    static int default_device_setup;   // value new grids start with (mmgh_set_option "device_setup")
+    static const int kDeviceSetupMin = 20000;
     // domain decomposition: bcFlags_ == 3 marks a GHOST point (copy of a point owned by
     // another rank): searchable as a stencil neighbour, never relaxed, no matrix row.
     // Owned points come first, ghosts last, grouped by owner.
@@ -120,6 +126,12 @@ public:
     std::pair<VectorXd, vector<int>> derivy_weights(int pointID);                  // grid.cpp:343-380
     std::pair<VectorXd, vector<int>> derivz_weights(int pointID);                  // 3-D extension
     std::pair<VectorXd, vector<int>> pointInterpWeights(Point point, int polyDeg); // grid.cpp:687-712
+    // The same stencils for MANY evaluation points at once: kNN on the host threads, the
+    // (ss+pt)^2 saddle systems on the device.  ops: 0 laplace, 1 d/dx, 2 d/dy, 3 d/dz, 4 interpolation.
+    // nbr[e*ss + j] / w[(o*n_eval + e)*ss + j].  Returns false (nothing computed) when the batch is
+    // to be done by the host path instead.
+    bool batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
+                          const vector<int> &ops, vector<int> &nbr, vector<double> &w);
 
     int getSize();
     int getStencilSize();

@@ -427,14 +427,18 @@ void mmgh_grid_local_map(void *gp, int *gid, int *ghost_owner)
 //   flags_in: 0 interior, 1 Dirichlet boundary (owned), 3 margin point owned by `owner[i]`
 //   gid     : global id of every point
 // Margin points no owned stencil references are dropped; the rest become ghosts (sorted by
-// owner, then gid).  Operator: graph Laplacian (kind 2) on `stencil` nearest neighbours.
+// owner, then gid).  Operator: kind 2 graph Laplacian on `stencil` nearest neighbours; kind 0 the
+// RBF-FD Laplacian of degree `polydeg` (stencil must then be Grid::stencilSizeFor(polydeg, dim)) --
+// a rank's rows are exactly the rows a single global grid would hold.
 void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, const int *gid, const int *owner, int dim,
-                             int stencil, int tile_points, int lanes_per_row, double omega, int iters)
+                             int stencil, int tile_points, int lanes_per_row, double omega, int iters, int kind, int polydeg)
 {
     Grid *out = nullptr;
     const int rc = guard([&]() {
         std::vector<Point> pts = to_points(xyz, n);
-        GridProperties props = make_props(3, dim, omega, iters);
+        GridProperties props = make_props(polydeg > 0 ? polydeg : 3, dim, omega, iters);
+        if (kind == 0 && stencil != Grid::stencilSizeFor(props.polyDeg, dim))
+            throw std::invalid_argument("create_local: RBF-FD rows need stencil == stencilSizeFor(polydeg, dim)");
         props.stencilSize = stencil;
         // pass 1: which margin points are referenced by owned stencils
         std::vector<char> used((size_t)n, 0);
@@ -490,7 +494,8 @@ void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, cons
         g->origIndex_ = lgid;  // apply_order permutes this along with the points
         for (int i : ghosts) g->ghostOwner_.push_back(owner[i]);
         g->mc_order_points(tile_points);
-        g->build_graph_laplacian();
+        if (kind == 0) g->build_laplacian();
+        else g->build_graph_laplacian();
         out = g;
     });
     if (rc) { delete out; return nullptr; }
@@ -528,6 +533,13 @@ void mmgh_write_vector_txt(const double *v, int n, const char *fname) { writeVec
 int mmgh_order_from_txt(const char *fname, int nv) { return (int)orderFromTxt(fname, nv).size(); }
 int mmgh_write_msh(const char *fname, const double *xyz, int n) { return writePointsToMshFile(fname, to_points(xyz, n)) ? 0 : 1; }
 // k nearest neighbours of point `pid` with the reference's exclusion rule
+// "device_setup": -1 automatic, 0 host threads, 1 batched on the MI355X (Grid::device_setup_ of grids created afterwards)
+int mmgh_set_option(const char *name, int value)
+{
+    if (name && std::string(name) == "device_setup") { Grid::default_device_setup = value; return 0; }
+    g_herr = "mmgh_set_option: unknown option";
+    return 1;
+}
 int mmgh_grid_knn(void *gp, int pid, int k, int *out)
 {
     Grid *g = static_cast<Grid *>(gp);

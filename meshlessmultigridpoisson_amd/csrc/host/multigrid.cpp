@@ -55,9 +55,24 @@ Multigrid::SparseColMajor *Multigrid::buildInterpMatrix(Grid *base, Grid *target
 {
     const int nt = target->getSize();
     const int deg = fracStep_ ? base->properties_.polyDeg : grids_.back().second->properties_.polyDeg;
+    base->kNearestNeighbors(target->points_[0], false, false, 1);  // builds the search grid once, single-threaded
+    {
+        // batched on the device when it pays: kNN on the host threads, dense solves on the MI355X
+        vector<int> nbr;
+        vector<double> w;
+        if (base->batched_stencils(target->points_, nullptr, false, deg, {4 /* interpolation */}, nbr, w)) {
+            const int ss = Grid::stencilSizeFor(deg, base->dim_);
+            vector<Triplet> trip;
+            trip.reserve((size_t)nt * (size_t)ss);
+            for (int i = 0; i < nt; ++i)
+                for (int j = 0; j < ss; ++j) trip.emplace_back(i, nbr[(size_t)i * ss + j], w[(size_t)i * ss + j]);
+            SparseColMajor *m = new SparseColMajor(nt, base->getSize(), false);
+            m->setFromTriplets(trip.begin(), trip.end());
+            return m;
+        }
+    }
     std::vector<std::vector<double>> W((size_t)nt);
     std::vector<vector<int>> NB((size_t)nt);
-    base->kNearestNeighbors(target->points_[0], false, false, 1);  // builds the search grid once, single-threaded
     int nth = base->setup_threads_ > 0 ? base->setup_threads_ : (int)std::thread::hardware_concurrency();
     nth = std::max(1, std::min(nth, nt / 64 + 1));
     std::atomic<int> next{0};

@@ -388,3 +388,35 @@ def test_distributed_vcycle_matches_hybrid_oracle(neumann):
     if neumann:
         x[-1] = ranks[0].lv[-1].x[-1]
     assert np.abs(x - om.levels[-1].x).max() <= 1e-10 * np.abs(om.levels[-1].x).max()
+
+
+def test_slab_cloud_rbf_rows_reproduce_polynomials_across_the_cut():
+    """bench.py --gpus N with the reference's RBF-FD operator: every rank assembles the rows of its
+    owned points from its own layers + margin (Grid::build_laplacian on the local cloud).  A row must
+    be the row a single global grid would hold: its columns (owned or ghost) carry the global ids of
+    the true nearest neighbours, and the stencil reproduces the Laplacian of every polynomial of
+    degree <= 3 -- also for rows whose stencil straddles the cut."""
+    from meshlessmultigridpoisson_amd import _host as host
+    nr, nside, dim, K = 2, 12, 3, 50
+    h = 1.0 / (nside - 1)
+    for r in range(nr):
+        pts, flags, gid, owner = host.slab_cloud(r, nr, nside, dim=dim, margin=5)
+        coords = {int(g): p for g, p in zip(gid, pts)}
+        s = host.Grid.create_local(pts, flags, gid, owner, dim, K, tile_points=256, lanes_per_row=2,
+                                   kind=host.KIND_DIRICHLET, polydeg=3)
+        no, lgid, gown = s.local_map()
+        la = s.level_arrays()
+        xyz = np.array([coords[int(g)] for g in lgid])          # coordinates by GLOBAL id, not by local position
+        lxyz, _ = s.points()
+        assert np.array_equal(xyz, lxyz)                        # local storage and the id map agree
+        rp, col, val = la["rowptr"], la["col"], la["val"]
+        assert np.all(np.diff(rp)[:no] == K) and rp[no] == rp[-1]
+        near_cut = np.abs(xyz[:no, 0] - (1.0 if r == 0 else 1.0 + h)) < 1.5 * h
+        assert near_cut.sum() > 0 and (col[rp[np.flatnonzero(near_cut)[0]]:rp[np.flatnonzero(near_cut)[0] + 1]] >= no).any()
+        for (a, b, c), lapf in (((0, 0, 0), lambda q: 0 * q[:, 0]), ((1, 0, 0), lambda q: 0 * q[:, 0]),
+                                ((2, 0, 0), lambda q: 2 + 0 * q[:, 0]), ((1, 1, 0), lambda q: 0 * q[:, 0]),
+                                ((0, 2, 1), lambda q: 2 * q[:, 2]), ((3, 0, 0), lambda q: 6 * q[:, 0])):
+            p = xyz[:, 0] ** a * xyz[:, 1] ** b * xyz[:, 2] ** c
+            got = np.add.reduceat(val * p[col], rp[:no])
+            scale = np.add.reduceat(np.abs(val * p[col]), rp[:no]) + 1.0
+            assert (np.abs(got - lapf(xyz[:no])) / scale).max() <= 1e-8, (r, a, b, c)
