@@ -199,6 +199,18 @@ def main():
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the PMC counters of the committed profile of this same workload
+    # (profiles/collect.sh: rocprofv3 --pmc passes cannot run inside the timed process)
+    traffic, traffic_src = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if (pm["tiles"] == info["n_tiles"] and pm["interior_points_per_gpu"] == interior and pm["stencil"] == stencil
+                and launches <= sweeps_timed):
+            traffic = pm["bytes_per_launch"] / pm["sweeps_per_launch"] * (sweeps_timed / launches)
+            traffic_src = pm["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "fine-grid smoother Mpoints/s + achieved HBM GB/s vs roofline, 1/2/4/8 GPU",
@@ -229,7 +241,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src,
                 "kernel": "sweep_persistent_kernel<L,MAXP>" if launches <= sweeps_timed else "tile_kernel<L,MODE_SOR,MAXP>",
                 "launches": launches, "sweeps_in_launches": sweeps_timed,
                 "avg_launch_us": kern_ms * 1e3 / launches, "us_per_sweep": kern_ms * 1e3 / sweeps_timed,

@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nside", type=int, default=1000)
+    ap.add_argument("--dim", type=int, default=2, help="3: box clouds (BASELINE configs[2] with --nside 216 --levels 4 --polydeg 3)")
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--polydeg", type=int, default=4)
@@ -28,18 +29,21 @@ def main():
     _capi.set_option("persistent_sweep", a.persistent)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
-    clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
+    if a.dim == 3:
+        clouds = [_host.box_cloud(n, 3, seed=12345 + i) for i, n in enumerate(sides)]
+    else:
+        clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
     polys = [3] * (a.levels - 1) + [a.polydeg]
-    mg = _host.Multigrid(clouds, polys, neumann=False, ordering=_host.ORDER_MC, tile_points=0)
+    mg = _host.Multigrid(clouds, polys, dim=a.dim, neumann=False, ordering=_host.ORDER_MC, tile_points=0)
     t_setup = time.perf_counter() - t0
     res, ms = mg.vcycles(3)  # warm-up, creates the device hierarchy
     t0 = time.perf_counter()
     res, ms = mg.vcycles(a.cycles)
     wall = time.perf_counter() - t0
-    out = {"workload": f"2-D {sides[-1]}^2 = {sides[-1] ** 2} points, {a.levels} levels {sides}, polyDeg {polys}",
+    out = {"workload": f"{a.dim}-D {sides[-1]}^{a.dim} = {sides[-1] ** a.dim} points, {a.levels} levels {sides}, polyDeg {polys}",
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
            "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
-           "fine_points_per_s_per_vcycle": sides[-1] ** 2 / (ms / a.cycles * 1e-3)}
+           "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
     if a.oracle_cycles:
         om = mg.oracle()  # state after the GPU cycles; compare the continuation
         t0 = time.perf_counter()

@@ -67,6 +67,14 @@ def main():
             spl = rl.get("sweeps_in_launches", rl["launches"]) / rl["launches"]
             lines.append(f"algorithmic bytes per sweep: {alg_sweep:.1f} MB; PMC traffic {traffic:.1f} MB per launch of "
                          f"{spl:.0f} sweeps = {traffic/spl:.1f} MB per sweep (ratio {traffic/spl/alg_sweep:.2f})")
+    if bench and traffic:
+        # what bench.py reports as roofline.traffic (only for a run of the same shape)
+        json.dump({"source": f"profiles/{tag}_summary.md", "kernel": rl["kernel"], "bytes_per_launch": traffic * 1e6,
+                   "sweeps_per_launch": rl.get("sweeps_in_launches", rl["launches"]) / rl["launches"],
+                   "tiles": cfg["tiles"], "tile_points": cfg["tile_points"], "interior_points_per_gpu": cfg["interior_points_per_gpu"],
+                   "stencil": cfg["stencil"], "collection": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes; "
+                   "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 counts 128-B read requests as 64 B)"},
+                  open(os.path.join(here, "pmc_traffic.json"), "w"), indent=1)
     open(os.path.join(here, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
