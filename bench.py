@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--force-dd", action="store_true",
                     help="take the domain-decomposition code path (slab-local system, RCCL communicator, exchange "
                          "lists) even with one rank -- rehearsal of the N>1 path on a 1-GPU box")
+    ap.add_argument("--exchange", choices=("sweep", "phase"), default="sweep",
+                    help="N>1: ghost refresh once per sweep (block-hybrid Gauss-Seidel, default) or before every phase "
+                         "(exact: the sequential reference sweep on the global system)")
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
     return ap.parse_args()
@@ -151,6 +154,8 @@ def main():
     lv = _capi.Level.borrow(grid.device_level(), sz["n"], sz["a_size"])
     if dd:
         lv.set_exchange(n_owned, nbr, sp, si, rp)
+        if a.exchange == "phase":
+            lv.set_exchange_mode(1)
     info = lv.info()
     t_setup = time.perf_counter() - t_setup
     interior = info["sor_rows"]
@@ -235,8 +240,10 @@ def main():
                 "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches <= sweeps_timed), "sweeps_executed": a.warmup + a.steps + sweeps_timed + 2 * a.verify,
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if not dd else
-                               f"domain decomposition: {world} x-slabs, RCCL ghost exchange once per sweep "
-                               f"(block-hybrid Gauss-Seidel), {sz['n'] - n_owned} ghost values per rank",
+                               f"domain decomposition: {world} x-slabs, RCCL ghost exchange "
+                               + ("once per sweep (block-hybrid Gauss-Seidel)" if a.exchange == "sweep" else
+                                  "before every phase (exact sequential Gauss-Seidel on the global system)")
+                               + f", {sz['n'] - n_owned} ghost values per rank",
                 "setup_seconds": round(t_setup, 1),
             },
             "roofline": {

@@ -68,6 +68,9 @@ typedef struct {
     int n_tiles;
     int tile_size;         /* points per tile when tile_ptr is NULL             */
     int lanes_per_row;     /* 1,2,4,8,16,32,64                                  */
+    const int *tile_phase; /* [n_tiles] or NULL: lower bound on the phase (stage of a sweep) of each tile;
+                              sub-domains pass the GLOBAL tile colours so that every rank numbers its
+                              phases alike (mmg_level_set_exchange_mode)        */
 } mmg_level_desc;
 
 /* Introspection of the packed device layout (for DESIGN/bench reporting). */
@@ -169,6 +172,16 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
 int mmg_comm_get_unique_id(char *id128);   /* 128 bytes; the caller broadcasts rank 0's */
 int mmg_comm_init(int rank, int nranks, const char *id128);
 int mmg_comm_finalize(void);
+/* Ghost refresh schedule of a distributed level (collective: every rank calls it after
+ * mmg_level_set_exchange).  per_phase = 0 (default): once per sweep -- block-hybrid Gauss-Seidel,
+ * foreign columns see the previous sweep.  per_phase = 1: before EVERY phase of a sweep -- the
+ * distributed sweep is then the reference's sequential Grid::sor loop (grid.cpp:112-145) in the
+ * global storage order (phase, rank, local order), i.e. the single-GPU / CPU residual history is
+ * preserved.  Verified at this call: fails with MMG_ERR_UNSUPPORTED (mode unchanged) when some
+ * ghost value is relaxed by its owner in a phase that also reads it here. */
+int mmg_level_set_exchange_mode(mmg_level *lv, int per_phase);
+/* phase of the sweep in which each point is relaxed (-1: never); n = level points */
+int mmg_level_point_phases(mmg_level *lv, int *phase, int n);
 /* nbr_rank[n_nbr]; send_idx[send_ptr[k]..send_ptr[k+1]) = local indices of owned
  * points whose values neighbour k needs; ghosts received from neighbour k land at
  * x[n_owned_points + recv_ptr[k] .. n_owned_points + recv_ptr[k+1]). */

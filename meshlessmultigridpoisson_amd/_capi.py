@@ -23,7 +23,8 @@ class LevelDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("a_size", C.c_int), ("rowptr", _ip), ("col", _ip), ("val", _dp),
                 ("bcflags", _ip), ("neumann_flag", C.c_int), ("omega", C.c_double), ("iters", C.c_int),
                 ("nb", C.c_int), ("btype", _ip), ("bptr", _ip), ("bpts", _ip), ("bvals", _dp),
-                ("tile_ptr", _ip), ("n_tiles", C.c_int), ("tile_size", C.c_int), ("lanes_per_row", C.c_int)]
+                ("tile_ptr", _ip), ("n_tiles", C.c_int), ("tile_size", C.c_int), ("lanes_per_row", C.c_int),
+                ("tile_phase", _ip)]
 
 
 class LevelInfo(C.Structure):
@@ -39,7 +40,7 @@ class LevelInfo(C.Structure):
 SYMBOLS = [
     "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
     "mmg_device_props", "mmg_auto_tile_points", "mmg_set_option", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
-    "mmg_level_set_exchange", "mmg_level_exchange",
+    "mmg_level_set_exchange", "mmg_level_set_exchange_mode", "mmg_level_point_phases", "mmg_level_exchange",
     "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
     "mmg_level_sor", "mmg_level_sweeps", "mmg_level_bound_eval_neumann", "mmg_level_residual",
@@ -195,7 +196,7 @@ def _pd(a):
 
 
 def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-              tile_ptr=None, tile_size=0, lanes_per_row=0):
+              tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
     """Returns (LevelDesc, keepalive) -- keepalive holds the numpy arrays."""
     keep = dict(rowptr=_i(rowptr), col=_i(col), val=_d(val), bcflags=_i(bcflags), btype=_i(btype),
                 bptr=_i(bptr), bpts=_i(bpts), bvals=_d(bvals))
@@ -213,6 +214,10 @@ def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, 
         keep["tile_ptr"] = _i(tile_ptr)
         d.tile_ptr = _pi(keep["tile_ptr"])
         d.n_tiles = len(keep["tile_ptr"]) - 1
+    if tile_phase is not None and tile_ptr is not None:
+        keep["tile_phase"] = _i(tile_phase)
+        assert len(keep["tile_phase"]) == d.n_tiles
+        d.tile_phase = _pi(keep["tile_phase"])
     d.tile_size = int(tile_size)
     d.lanes_per_row = int(lanes_per_row)
     return d, keep
@@ -231,9 +236,9 @@ class Level:
         return self
 
     def __init__(self, n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-                 x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0):
+                 x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
         d, keep = make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-                            tile_ptr, tile_size, lanes_per_row)
+                            tile_ptr, tile_size, lanes_per_row, tile_phase)
         self.n, self.a_size = d.n, d.a_size
         self.h = C.c_void_p()
         check(lib().mmg_level_create(C.byref(self.h), C.byref(d)))
@@ -251,6 +256,15 @@ class Level:
         nbr, sp, si, rp = _i(nbr_rank), _i(send_ptr), _i(send_idx), _i(recv_ptr)
         check(lib().mmg_level_set_exchange(self.h, int(n_owned), len(nbr), _pi(nbr), sp.ctypes.data_as(_ip),
                                            si.ctypes.data_as(_ip) if si.size else None, rp.ctypes.data_as(_ip)))
+
+    def set_exchange_mode(self, per_phase):
+        """collective; raises MmgError (mode unchanged) when the exact schedule does not exist for this partition"""
+        check(lib().mmg_level_set_exchange_mode(self.h, int(per_phase)))
+
+    def point_phases(self):
+        ph = np.zeros(self.n, dtype=np.int32)
+        check(lib().mmg_level_point_phases(self.h, ph.ctypes.data_as(_ip), self.n))
+        return ph
 
     def exchange(self):
         check(lib().mmg_level_exchange(self.h))

@@ -54,6 +54,7 @@ def lib():
         L.mmgh_grid_get_points.argtypes = [vp, _dp, _ip]
         L.mmgh_grid_get_boundaries.argtypes = [vp, _ip, _ip, _ip, _dp]
         L.mmgh_grid_get_tile_ptr.argtypes = [vp, _ip]
+        L.mmgh_grid_get_tile_phase.argtypes = [vp, _ip]
         for f in ("mmgh_grid_get_values", "mmgh_grid_get_source", "mmgh_grid_set_values", "mmgh_grid_set_source",
                   "mmgh_grid_residual", "mmgh_grid_residual_ratio"):
             getattr(L, f).argtypes = [vp, _dp]
@@ -231,6 +232,15 @@ class Grid:
         lib().mmgh_grid_get_tile_ptr(self.h, tp.ctypes.data_as(_ip))
         return tp
 
+    def tile_phase(self):
+        """Phase numbers (global tile colours) a sub-domain grid passes to libmmgp, or None."""
+        n = lib().mmgh_grid_get_tile_phase(self.h, None)
+        if n == 0:
+            return None
+        tc = np.zeros(n, dtype=np.int32)
+        lib().mmgh_grid_get_tile_phase(self.h, tc.ctypes.data_as(_ip))
+        return tc
+
     def values(self):
         x = np.zeros(self.sizes()["a_size"])
         _chk(lib().mmgh_grid_get_values(self.h, x.ctypes.data_as(_dp)))
@@ -407,16 +417,21 @@ class Multigrid:
         lib().mmgh_mg_level_part(self.h, l, int(nparts), part.ctypes.data_as(_ip))
         return part
 
-    def setup_exchange(self, rank, all_gather_object):
+    def setup_exchange(self, rank, all_gather_object, exact=False):
         """Distributed run: register every level's ghost exchange with the device
-        (mmg_level_set_exchange).  Needs mmg_comm_init to have been called."""
+        (mmg_level_set_exchange).  Needs mmg_comm_init to have been called.  exact: ghosts refreshed
+        before every phase (mmg_level_set_exchange_mode) -- the V-cycle then reproduces the undecomposed
+        (single-GPU / CPU reference) residual history; raises if some level admits no such schedule."""
         from . import _capi
         for l in range(self.nlevels):
             g = self.grid(l)
             no, gid, gown = g.local_map()
             nbr, sp, si, rp = build_exchange_lists(rank, no, gid, gown, all_gather_object)
             s = g.sizes()
-            _capi.Level.borrow(g.device_level(), s["n"], s["a_size"]).set_exchange(no, nbr, sp, si, rp)
+            lv = _capi.Level.borrow(g.device_level(), s["n"], s["a_size"])
+            lv.set_exchange(no, nbr, sp, si, rp)
+            if exact:
+                lv.set_exchange_mode(1)
 
     @property
     def nlevels(self):

@@ -220,6 +220,12 @@ struct mmg_level {
     int workers = 0;
     // domain decomposition (mmg_level_set_exchange)
     bool distributed = false;
+    // exact mode: ghosts refreshed before EVERY phase (mmg_level_set_exchange_mode), all ranks walk
+    // `global_phases` phases in lockstep
+    bool exchange_per_phase = false;
+    int global_phases = 0;
+    std::vector<int32_t> point_phase;   // host: phase in which each point is relaxed (-1 never)
+    std::vector<uint64_t> ghost_mask;   // host: phases of the rows referencing each ghost
     int n_owned = 0;
     std::vector<int> nbr, send_ptr, recv_ptr;
     DevBuf<int32_t> send_idx;
@@ -296,6 +302,7 @@ int exchange_vec(mmg_level *lv, double *vec)
 bool use_single_launch(const mmg_level *lv)
 {
     if (lv->A.exact || lv->A.n_phases() <= 1 || lv->workers <= 0) return false;
+    if (lv->distributed && lv->exchange_per_phase) return false;  // an exchange sits between the phases
     if (g_persistent_sweep == 0) return false;
     if (g_persistent_sweep == 1) return lv->A.n_tiles > lv->workers;
     return true;
@@ -351,6 +358,20 @@ int sweep_some(mmg_level *lv, int k, int *done)
         HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
         if ((erc = mark_event())) return erc;
         *done = ns;
+    } else if (lv->distributed && lv->exchange_per_phase) {
+        // exact domain-decomposed Gauss-Seidel: a phase reads the foreign values written by all
+        // earlier phases of THIS sweep (the caller refreshed the ghosts before phase 0); every
+        // rank walks the same number of phases, the exchanges pair up
+        *done = 1;
+        for (int ph = 0; ph < lv->global_phases; ++ph) {
+            if (ph > 0 && (erc = exchange(lv))) return erc;
+            if (ph >= lv->A.n_phases()) continue;
+            a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
+            a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
+            if ((erc = mark_event())) return erc;
+            HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
+            if ((erc = mark_event())) return erc;
+        }
     } else {
         *done = 1;
         for (int ph = 0; ph < lv->A.n_phases(); ++ph) {
@@ -762,6 +783,10 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;
         if ((rc = lv->A.upload(P))) return rc;
+        if (!level_point_phases(*d, P, &lv->point_phase, &lv->ghost_mask).empty()) {
+            lv->point_phase.clear();  // exact exchange mode unavailable, the once-per-sweep mode still is
+            lv->ghost_mask.clear();
+        }
     }
 
     // ---- plan B: Neumann rows --------------------------------------------------
@@ -1028,6 +1053,53 @@ int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const i
     HIPC(lv->scalS.alloc(1));
     lv->n_owned = n_owned_points;
     lv->distributed = true;
+    return MMG_OK;
+}
+
+int mmg_level_set_exchange_mode(mmg_level *lv, int per_phase)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "set_exchange_mode: null level");
+    if (!per_phase) { lv->exchange_per_phase = false; return MMG_OK; }
+    if (!lv->distributed) return fail(MMG_ERR_INVALID, "set_exchange_mode: mmg_level_set_exchange has not been called");
+    if (lv->point_phase.size() != (size_t)lv->n)
+        return fail(MMG_ERR_UNSUPPORTED, "set_exchange_mode: level has no phase map (more than 64 phases per sweep)");
+    // collective: every rank learns in which phase the OWNER relaxes each of its ghosts, through
+    // the value exchange itself
+    DevBuf<double> tmp;
+    std::vector<double> ph((size_t)lv->a_size, -1.0);
+    for (int i = 0; i < lv->n_owned; ++i) ph[(size_t)i] = (double)lv->point_phase[(size_t)i];
+    HIPC(tmp.upload(ph.data(), ph.size()));
+    int rc = exchange_vec(lv, tmp.p);
+    if (rc) return rc;
+    HIPC(hipMemcpyAsync(ph.data(), tmp.p, sizeof(double) * ph.size(), hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    double stat[2] = {0.0, (double)lv->A.n_phases()};  // conflicts (sum over ranks), phases (max over ranks)
+    for (int j = lv->n_owned; j < lv->n; ++j) {
+        const int q = (int)ph[(size_t)j];
+        if (q >= 0 && q < 64 && ((lv->ghost_mask[(size_t)j] >> q) & 1ull)) stat[0] += 1.0;
+    }
+    if (g_rccl.comm && g_rccl.nranks > 1) {
+        DevBuf<double> d;
+        HIPC(d.upload(stat, 2));
+        NCCLC(g_rccl.AllReduce(d.p, d.p, 1, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
+        NCCLC(g_rccl.AllReduce(d.p + 1, d.p + 1, 1, kNcclDouble, 2 /* ncclMax */, g_rccl.comm, g_stream));
+        HIPC(hipMemcpyAsync(stat, d.p, sizeof(stat), hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+    }
+    if (stat[0] > 0.0)
+        return fail(MMG_ERR_UNSUPPORTED, "set_exchange_mode: " + std::to_string((long long)stat[0]) +
+                                             " ghost value(s) are relaxed by their owner in a phase that also reads them here; "
+                                             "no sequential order reproduces that (re-tile with an even number of slabs per rank)");
+    lv->global_phases = (int)stat[1];
+    lv->exchange_per_phase = true;
+    return MMG_OK;
+}
+
+int mmg_level_point_phases(mmg_level *lv, int *phase, int n)
+{
+    if (!lv || !phase || n != lv->n) return fail(MMG_ERR_INVALID, "point_phases: bad argument");
+    if (lv->point_phase.size() != (size_t)lv->n) return fail(MMG_ERR_UNSUPPORTED, "point_phases: no phase map");
+    for (int i = 0; i < n; ++i) phase[i] = lv->point_phase[(size_t)i];
     return MMG_OK;
 }
 

@@ -93,6 +93,8 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         s.mult_col = d.neumann_flag ? n : -1;
         s.L = L;
         s.exact = exact;
+        // hints index the caller's tiles: dropped once tiles had to be split
+        s.tile_phase_hint = (attempt == 0 && d.tile_ptr && d.n_tiles > 0) ? d.tile_phase : nullptr;
         err = build_plan(s, out);
         if (err.empty() || err.rfind("tile-too-large", 0) != 0) return err;
         std::vector<int32_t> split;  // halve every tile and retry
@@ -105,6 +107,33 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         pt_tile.swap(split);
     }
     return err;
+}
+
+std::string level_point_phases(const mmg_level_desc &d, const Plan &A, std::vector<int32_t> *phase,
+                               std::vector<uint64_t> *ghost_mask)
+{
+    const int n = d.n;
+    phase->assign((size_t)n, -1);
+    ghost_mask->assign((size_t)n, 0);
+    if (A.n_phases() > 64) return "more than 64 phases per sweep";
+    for (int ph = 0; ph < A.n_phases(); ++ph)
+        for (int k = A.phase_ptr[ph]; k < A.phase_ptr[ph + 1]; ++k) {
+            const TileDesc &td = A.tiles[(size_t)A.phase_tiles[k]];
+            for (uint32_t i = td.row0; i < td.row0 + td.n_own && i < (uint32_t)n; ++i)
+                if (d.bcflags[i] == 0) (*phase)[i] = ph;
+        }
+    bool has_ghost = false;
+    for (int i = 0; i < n && !has_ghost; ++i) has_ghost = d.bcflags[i] == 3;
+    for (int i = 0; i < n; ++i) {
+        if (d.bcflags[i] != 0) continue;
+        if ((*phase)[i] < 0) return "an interior row belongs to no tile";
+        if (!has_ghost) continue;  // no ghost columns: the O(nnz) scan is not needed
+        for (int p = d.rowptr[i]; p < d.rowptr[i + 1]; ++p) {
+            const int c = d.col[p];
+            if (c >= 0 && c < n && d.bcflags[c] == 3 && d.val[p] != 0.0) (*ghost_mask)[c] |= 1ull << (*phase)[i];
+        }
+    }
+    return std::string();
 }
 
 std::string build_boundary_lists(const mmg_level_desc &d, BoundaryLists *out)

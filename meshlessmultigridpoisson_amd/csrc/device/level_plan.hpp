@@ -19,6 +19,14 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
 // a tile == its points.  Tile boundaries come from desc.tile_ptr or tile_size.
 std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false);
 
+// Domain decomposition, exact (per-phase) ghost exchange: phase[i] = phase of the sweep in which
+// point i is relaxed by plan A (-1: never relaxed); ghost_mask[j] (ghost points, bcflags == 3) = bit
+// set of the phases of the relaxed rows that reference j with a nonzero coefficient.  A ghost whose
+// OWNER relaxes it in a phase contained in ghost_mask[j] would be read and written in the same
+// phase: no sequential Gauss-Seidel order reproduces that, the exact mode is refused.
+std::string level_point_phases(const mmg_level_desc &d, const Plan &A, std::vector<int32_t> *phase,
+                               std::vector<uint64_t> *ghost_mask);
+
 // Boundary bookkeeping of a level (deduplicated, last writer wins).
 struct BoundaryLists {
     std::vector<int32_t> dir_idx, dir_src;  // Dirichlet points and the position of their value in bvals

@@ -333,7 +333,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         }
         P.dep_ptr.assign((size_t)s.n_tiles + 1, 0);
         for (int t = 0; t < s.n_tiles; ++t) {
-            int ph = 0;
+            int ph = s.tile_phase_hint ? std::max(0, (int)s.tile_phase_hint[t]) : 0;
             for (int32_t u : dep[t]) ph = std::max(ph, phase[u] + 1);
             phase[t] = ph;
             n_phases = std::max(n_phases, ph + 1);

@@ -117,6 +117,10 @@ struct PlanSpec {
     int L = 4;
     int n_threads = 0;          // 0 = hardware concurrency
     bool exact = false;         // layout for the exact-arithmetic kernels: L = 1, no entries-per-lane cap
+    // Optional lower bound on the phase of each tile (in-place plans).  A distributed level passes the
+    // tile colours of the GLOBAL colouring, so that all ranks number their phases alike
+    // (mmg_level_set_exchange_mode); any value >= the dependency-derived phase keeps the schedule exact.
+    const int32_t *tile_phase_hint = nullptr;
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).

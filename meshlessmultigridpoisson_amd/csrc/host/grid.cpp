@@ -642,9 +642,15 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<in
         for (size_t t = 0; t + 1 < tile_ptr_.size(); ++t) {
             int cnt = 0;
             for (int i = tile_ptr_[t]; i < tile_ptr_[t + 1]; ++i) cnt += part[(size_t)i] == rank;
-            if (cnt) g->tile_ptr_.push_back(g->tile_ptr_.back() + cnt);
+            if (cnt) {
+                g->tile_ptr_.push_back(g->tile_ptr_.back() + cnt);
+                if (tile_colour_.size() + 1 == tile_ptr_.size()) g->tile_colour_.push_back(tile_colour_[t]);  // GLOBAL colour
+            }
         }
-        if (g->tile_ptr_.back() != no) g->tile_ptr_.clear();  // points outside every tile: let libmmgp tile uniformly
+        if (g->tile_ptr_.back() != no) {  // points outside every tile: let libmmgp tile uniformly
+            g->tile_ptr_.clear();
+            g->tile_colour_.clear();
+        }
     }
     return g;
 }
@@ -696,6 +702,7 @@ void Grid::apply_order(const vector<int> &order)
         for (int &p : b.bcPoints) p = old2new[(size_t)p];
     knn_ = mmgh::CellGrid();
     tile_ptr_.clear();
+    tile_colour_.clear();
 }
 
 // grid.cpp:713-776
@@ -773,6 +780,7 @@ mmg_level *Grid::device()
     if (!tile_ptr_.empty()) {
         d.tile_ptr = tile_ptr_.data();
         d.n_tiles = (int)tile_ptr_.size() - 1;
+        if (nOwned_ >= 0 && tile_colour_.size() + 1 == tile_ptr_.size()) d.tile_phase = tile_colour_.data();
     }
     d.tile_size = tile_size_;
     d.lanes_per_row = lanes_per_row_;

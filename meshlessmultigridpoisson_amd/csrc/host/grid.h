@@ -52,6 +52,8 @@ public:
     // ---- additions (not in the reference) -------------------------------------
     int dim_ = 2;                // 3 enables the 3-D extension (distance, basis, PHS Laplacian)
     vector<int> tile_ptr_;       // tile boundaries produced by mc_order_points()
+    vector<int> tile_colour_;    // colour of each tile (non-decreasing along the storage order); sub-domains hand
+                                 // it to libmmgp as phase numbers so that all ranks number their phases alike
     int lanes_per_row_ = 0;      // device layout hints, 0 = automatic
     int tile_size_ = 0;
     int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy

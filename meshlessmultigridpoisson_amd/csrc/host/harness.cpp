@@ -274,6 +274,14 @@ void mmgh_grid_get_tile_ptr(void *gp, int *tp)
     Grid *g = static_cast<Grid *>(gp);
     std::memcpy(tp, g->tile_ptr_.data(), sizeof(int) * g->tile_ptr_.size());
 }
+// colours of the tiles when the grid hands them to libmmgp as phase numbers (sub-domains); returns the count
+int mmgh_grid_get_tile_phase(void *gp, int *tc)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    if (g->nOwned_ < 0 || g->tile_colour_.size() + 1 != g->tile_ptr_.size()) return 0;
+    if (tc) std::memcpy(tc, g->tile_colour_.data(), sizeof(int) * g->tile_colour_.size());
+    return (int)g->tile_colour_.size();
+}
 int mmgh_grid_get_values(void *gp, double *x) { return guard([&]() { Grid *g = static_cast<Grid *>(gp); std::memcpy(x, g->values_->data(), sizeof(double) * (size_t)g->values_->rows()); }); }
 int mmgh_grid_get_source(void *gp, double *b) { return guard([&]() { Grid *g = static_cast<Grid *>(gp); std::memcpy(b, g->source_.data(), sizeof(double) * (size_t)g->source_.rows()); }); }
 void mmgh_grid_set_values(void *gp, const double *x)

@@ -152,6 +152,10 @@ void Grid::mc_order_points(int tile_points)
                 if (ext[a2] / m[a2] > ext[best] / m[best]) best = a2;
             m[best]++;
         }
+        // sub-domains (x-slab partitions): an even number of x-slabs per rank makes the tiles on
+        // either side of a cut differ in x-parity, hence in colour -- what the exact (per-phase)
+        // ghost exchange needs (mmg_level_set_exchange_mode)
+        if (nOwned_ >= 0 && (m[0] & 1)) m[0]++;
         auto by_axis = [&](int ax) {
             return [this, ax](int x, int y) {
                 const double vx = comp(points_[(size_t)x], ax), vy = comp(points_[(size_t)y], ax);
@@ -291,6 +295,8 @@ void Grid::mc_order_points(int tile_points)
     vector<int> order;
     order.reserve((size_t)n);
     vector<int> tptr(1, 0);
+    vector<int> tcolour;
+    for (int t : torder) tcolour.push_back(tcol[(size_t)t]);
     for (int t : torder) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1];
         vector<int> loc(idx.begin() + b, idx.begin() + e);
@@ -306,4 +312,5 @@ void Grid::mc_order_points(int tile_points)
     order.insert(order.end(), ghost_idx.begin(), ghost_idx.end());
     apply_order(order);
     tile_ptr_ = tptr;
+    tile_colour_ = tcolour;
 }

@@ -99,6 +99,8 @@ def emu_lib():
         L.emu_level_residual.restype = C.c_double
         L.emu_level_sor_phases.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
         L.emu_level_owned_sum.argtypes = [C.c_void_p, _dp]
+        L.emu_level_sor_one_phase.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int]
+        L.emu_level_point_phases.argtypes = [C.c_void_p, C.c_void_p, _ip, C.POINTER(C.c_ulonglong)]
         L.emu_level_owned_sum.restype = C.c_double
         L.emu_level_stream_bytes.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.restype = C.c_longlong
@@ -110,12 +112,14 @@ def emu_lib():
 
 
 class EmuLevel:
-    def __init__(self, la, tile_ptr=None, tile_size=0, lanes_per_row=0):
+    def __init__(self, la, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
         from meshlessmultigridpoisson_amd import _capi
         d, self._keep = _capi.make_desc(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], la["neumann"],
                                         la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"],
-                                        tile_ptr, tile_size, lanes_per_row)
+                                        tile_ptr, tile_size, lanes_per_row, tile_phase)
         self.L = emu_lib()
+        self._desc = d
+        self._neumann = bool(la["neumann"])
         self.h = self.L.emu_level_create(C.byref(d))
         if not self.h:
             raise RuntimeError(self.L.emu_last_error().decode())
@@ -137,6 +141,19 @@ class EmuLevel:
 
     def sor_phases(self):
         self.L.emu_level_sor_phases(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp), self.omega)
+
+    def sor_one_phase(self, ph):
+        return self.L.emu_level_sor_one_phase(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp),
+                                              C.c_double(self.omega), int(ph))
+
+    def point_phases(self):
+        n = len(self.x) - (1 if self._neumann else 0)
+        ph = np.zeros(n, dtype=np.int32)
+        gm = np.zeros(n, dtype=np.uint64)
+        rc = self.L.emu_level_point_phases(self.h, C.byref(self._desc), ph.ctypes.data_as(_ip),
+                                           gm.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+        assert rc == 0, self.L.emu_last_error()
+        return ph, gm
 
     def owned_sum(self):
         return float(self.L.emu_level_owned_sum(self.h, self.x.ctypes.data_as(_dp)))

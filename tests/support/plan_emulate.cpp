@@ -190,6 +190,28 @@ void emu_level_sor_phases(void *h, double *x, const double *b, double omega)
     const double lam = e->neumann ? x[e->n] : 0.0;
     run_plan(e->A, M_SOR, x, nullptr, nullptr, b, omega, lam, (size_t)e->a_size, nullptr);
 }
+// one phase of a sweep (exact domain-decomposed schedule: the test refreshes the ghosts in between)
+int emu_level_sor_one_phase(void *h, double *x, const double *b, double omega, int ph)
+{
+    Emu *e = static_cast<Emu *>(h);
+    if (ph < 0 || ph >= e->A.n_phases()) return 0;
+    const double lam = e->neumann ? x[e->n] : 0.0;
+    std::vector<double> snap(x, x + e->a_size);
+    for (int k = e->A.phase_ptr[ph]; k < e->A.phase_ptr[ph + 1]; ++k)
+        run_tile(e->A, e->A.phase_tiles[k], M_SOR, snap.data(), x, b, omega, lam, nullptr);
+    return e->A.phase_ptr[ph + 1] - e->A.phase_ptr[ph];
+}
+// the library's own phase map and ghost masks (level_plan.cpp:level_point_phases)
+int emu_level_point_phases(void *h, const mmg_level_desc *d, int *phase, unsigned long long *ghost_mask)
+{
+    Emu *e = static_cast<Emu *>(h);
+    std::vector<int32_t> ph;
+    std::vector<uint64_t> gm;
+    const std::string err = level_point_phases(*d, e->A, &ph, &gm);
+    if (!err.empty()) { g_err = err; return 1; }
+    for (int i = 0; i < e->n; ++i) { phase[i] = ph[(size_t)i]; ghost_mask[i] = gm[(size_t)i]; }
+    return 0;
+}
 double emu_level_owned_sum(void *h, const double *x)
 {
     Emu *e = static_cast<Emu *>(h);

@@ -29,7 +29,7 @@ def _global_problem(host, nside=33, tile=128, seed=21):
 
 def _local_level(sub):
     la = sub.level_arrays()
-    return H.EmuLevel(la, tile_ptr=sub.tile_ptr(), lanes_per_row=4), la
+    return H.EmuLevel(la, tile_ptr=sub.tile_ptr(), lanes_per_row=4, tile_phase=sub.tile_phase()), la
 
 
 def _check_against_oracle(la_glob, part, nparts, results, nsweeps):
@@ -233,14 +233,16 @@ def test_gloo_world_size_2(tmp_path):
 class _Rank:
     """One rank's view of a decomposed hierarchy, arithmetic by the plan interpreter."""
 
-    def __init__(self, host, sub, rank):
+    def __init__(self, host, sub, rank, hints=False):
         self.nl = sub.nlevels
         self.lv, self.maps, self.la, self.R, self.P = [], [], [], [None] * self.nl, [None] * self.nl
         for l in range(self.nl):
             g = sub.grid(l)
             la = g.level_arrays()
             self.la.append(la)
-            self.lv.append(H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=4))
+            # hints: the GLOBAL tile colours as phase numbers, as Grid::device() passes them for sub-domains
+            self.lv.append(H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=4,
+                                      tile_phase=g.tile_phase() if hints else None))
             self.maps.append(g.local_map())
             self.R[l] = sub.transfer("R", l)
             self.P[l] = sub.transfer("P", l)
@@ -270,13 +272,20 @@ def _exchange(ranks, l, get, put):
             put(rk)[no + rp[k]: no + rp[k + 1]] = out[(int(q), r)]
 
 
-def _dist_sweeps(ranks, l, k):
+def _dist_sweeps(ranks, l, k, exact=False):
     neumann = ranks[0].la[l]["neumann"]
     n = [rk.la[l]["n"] for rk in ranks]
+    gmax = max(rk.lv[l].info()["n_phases"] for rk in ranks)
     for _ in range(k):
-        _exchange(ranks, l, lambda rk: rk.lv[l].x, lambda rk: rk.lv[l].x)
-        for rk in ranks:
-            rk.lv[l].sor_phases()
+        if exact:   # mmg_level_set_exchange_mode(per_phase = 1): ghosts refreshed before every phase
+            for ph in range(gmax):
+                _exchange(ranks, l, lambda rk: rk.lv[l].x, lambda rk: rk.lv[l].x)
+                for rk in ranks:
+                    rk.lv[l].sor_one_phase(ph)
+        else:
+            _exchange(ranks, l, lambda rk: rk.lv[l].x, lambda rk: rk.lv[l].x)
+            for rk in ranks:
+                rk.lv[l].sor_phases()
         if neumann:
             S = sum(rk.lv[l].owned_sum() for rk in ranks)          # ncclAllReduce
             for rk, nn in zip(ranks, n):
@@ -308,7 +317,7 @@ def _dist_residual(ranks, l):
     return nr / nb
 
 
-def _dist_vcycle(ranks):
+def _dist_vcycle(ranks, exact=False):
     """vcycle_dev (capi.hip) step by step, exchanges where the device does them."""
     nl = ranks[0].nl
     resid = _dist_residual(ranks, nl - 1)
@@ -324,7 +333,7 @@ def _dist_vcycle(ranks):
             if i != nl - 1:
                 e.x[:] = 0.0
             e.x[rk.dir_idx(i)] = 0.0 if i != nl - 1 else rk.la[i]["bvals"][: len(rk.dir_idx(i))]
-        _dist_sweeps(ranks, i, ranks[0].la[i]["iters"])
+        _dist_sweeps(ranks, i, ranks[0].la[i]["iters"], exact)
         _dist_residual(ranks, i)
         for rk in ranks:
             R = rk.R[i]
@@ -340,7 +349,7 @@ def _dist_vcycle(ranks):
         rk.lv[cur].x[rk.dir_idx(cur)] = 0.0
     for rk in ranks:
         rk.lv[0].x[:] = 0.0
-    _dist_sweeps(ranks, 0, 2 * ranks[0].la[0]["iters"])
+    _dist_sweeps(ranks, 0, 2 * ranks[0].la[0]["iters"], exact)
     for i in range(1, nl):
         _exchange(ranks, i - 1, lambda rk: rk.lv[i - 1].x, lambda rk: rk.lv[i - 1].x)
         for rk in ranks:
@@ -350,7 +359,7 @@ def _dist_vcycle(ranks):
             if not rk.la[i]["neumann"]:
                 corr[rk.dir_idx(i)] = 0.0
             rk.lv[i].x[:nf] += corr
-        _dist_sweeps(ranks, i, ranks[0].la[i]["iters"])
+        _dist_sweeps(ranks, i, ranks[0].la[i]["iters"], exact)
     return resid
 
 
@@ -380,6 +389,57 @@ def test_distributed_vcycle_matches_hybrid_oracle(neumann):
     for k in range(4):
         ro = om.vcycle_hybrid(parts, nparts)
         rd = _dist_vcycle(ranks)
+        assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
+    x = np.zeros_like(om.levels[-1].x)
+    for rk in ranks:
+        no, gid, _ = rk.maps[-1]
+        x[gid[:no]] = rk.lv[-1].x[:no]
+    if neumann:
+        x[-1] = ranks[0].lv[-1].x[-1]
+    assert np.abs(x - om.levels[-1].x).max() <= 1e-10 * np.abs(om.levels[-1].x).max()
+
+
+def _phase_conflicts(ranks, l):
+    """The collective check of mmg_level_set_exchange_mode, on the emulated ranks."""
+    bad = 0
+    for rk in ranks:
+        ph, gm = rk.lv[l].point_phases()
+        rk._ph = np.where(np.arange(len(ph)) < rk.maps[l][0], ph, -1).astype(np.float64)
+        rk._gm = gm
+    _exchange(ranks, l, lambda rk: rk._ph, lambda rk: rk._ph)
+    for rk in ranks:
+        no = rk.maps[l][0]
+        q = rk._ph[no:].astype(np.int64)
+        bad += int(((q >= 0) & (((rk._gm[no:] >> np.maximum(q, 0).astype(np.uint64)) & np.uint64(1)) == 1)).sum())
+    return bad
+
+
+@pytest.mark.parametrize("neumann", [False, True])
+def test_distributed_vcycle_exact_exchange_matches_plain_oracle(neumann):
+    """Exact mode (ghost refresh before every phase, phases numbered by the GLOBAL tile colours): the
+    distributed V-cycle is the reference's V-cycle itself -- residual history and iterate follow the
+    PLAIN oracle (oracle/mmg_oracle.c:orc_vcycle, the restatement of multigrid.cpp:62-110 with the
+    sequential Grid::sor) on the undecomposed hierarchy, to the 1e-10 of the single-GPU tests."""
+    from meshlessmultigridpoisson_amd import _host as host
+    nparts = 2
+    clouds = [host.square_cloud(n, seed=300 + i) for i, n in enumerate([13, 25, 41])]
+    mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
+    om = mg.oracle()
+    subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
+    ranks = [_Rank(host, s, r, hints=True) for r, s in enumerate(subs)]
+    for l in range(mg.nlevels):
+        needs = [{int(o): rk.maps[l][1][rk.maps[l][0]:][rk.maps[l][2] == o] for o in np.unique(rk.maps[l][2])} for rk in ranks]
+        for r, rk in enumerate(ranks):
+            no, gid, gown = rk.maps[l]
+            lst = host.build_exchange_lists(r, no, gid, gown, lambda obj: needs)
+            if rk.lists is None:
+                rk.lists = []
+            rk.lists.append(lst)
+    for l in range(mg.nlevels):
+        assert _phase_conflicts(ranks, l) == 0, f"level {l}"
+    for k in range(4):
+        ro = om.vcycle()
+        rd = _dist_vcycle(ranks, exact=True)
         assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
     x = np.zeros_like(om.levels[-1].x)
     for rk in ranks:
@@ -420,3 +480,111 @@ def test_slab_cloud_rbf_rows_reproduce_polynomials_across_the_cut():
             got = np.add.reduceat(val * p[col], rp[:no])
             scale = np.add.reduceat(np.abs(val * p[col]), rp[:no]) + 1.0
             assert (np.abs(got - lapf(xyz[:no])) / scale).max() <= 1e-8, (r, a, b, c)
+
+
+# ---- exact (per-phase) exchange: the distributed sweep IS the sequential reference sweep -----
+def _slab_ranks(host, nr, nside, dim, K, kind=None):
+    subs, maps = [], []
+    for r in range(nr):
+        pts, flags, gid, owner = host.slab_cloud(r, nr, nside, dim=dim, margin=5)
+        kw = {} if kind is None else dict(kind=kind, polydeg=3)
+        s = host.Grid.create_local(pts, flags, gid, owner, dim, K, tile_points=256, lanes_per_row=2, **kw)
+        subs.append(s)
+        maps.append(s.local_map())
+    needs = [{int(o): gid[no:][gown == o] for o in np.unique(gown)} for (no, gid, gown) in maps]
+    lists = [host.build_exchange_lists(r, no, gid, gown, lambda obj: needs) for r, (no, gid, gown) in enumerate(maps)]
+    return subs, maps, lists
+
+
+def _exchange_vecs(levels, maps, lists, vecs):
+    outbox = {}
+    for r, (nbr, sp, si, rp) in enumerate(lists):
+        for k, q in enumerate(nbr):
+            outbox[(r, int(q))] = vecs[r][si[sp[k]:sp[k + 1]]].copy()
+    for r, (nbr, sp, si, rp) in enumerate(lists):
+        no = maps[r][0]
+        for k, q in enumerate(nbr):
+            vecs[r][no + rp[k]: no + rp[k + 1]] = outbox[(int(q), r)]
+
+
+@pytest.mark.parametrize("nr", [2, 3])
+def test_per_phase_exchange_is_sequential_gauss_seidel(nr):
+    """mmg_level_set_exchange_mode(per_phase = 1): ghosts refreshed before every phase.  The ranks'
+    iterates must then be those of the reference's sequential row loop (grid.cpp:112-145, restated by
+    the plain oracle -- NOT the hybrid one) on the glued global system in the storage order
+    (phase, rank, local order).  Per-rank arithmetic: CPU interpreter of the packed plan; the phase
+    map and the conflict test are the library's own (level_plan.cpp:level_point_phases)."""
+    from meshlessmultigridpoisson_amd import _host as host
+    nside, dim, K = 12, 3, 50
+    subs, maps, lists = _slab_ranks(host, nr, nside, dim, K)
+    emus, las = zip(*[_local_level(s) for s in subs])
+    phases, masks = zip(*[e.point_phases() for e in emus])
+    # what the collective check of mmg_level_set_exchange_mode does: owner's phase of every ghost
+    phv = [np.where(np.arange(len(p)) < maps[r][0], p, -1).astype(np.float64) for r, p in enumerate(phases)]
+    _exchange_vecs(emus, maps, lists, phv)
+    for r in range(nr):
+        no = maps[r][0]
+        q = phv[r][no:].astype(np.int64)
+        conflict = (q >= 0) & (((masks[r][no:] >> np.maximum(q, 0).astype(np.uint64)) & np.uint64(1)) == 1)
+        assert not conflict.any(), f"rank {r}: {conflict.sum()} ghost(s) relaxed by the owner in a phase that reads them"
+        assert (q >= 0).any()                                  # some ghosts ARE relaxed points of the neighbour
+    gmax = max(e.info()["n_phases"] for e in emus)
+    # glue the global system in the order (phase, rank, local index); never-relaxed points last
+    keys = []
+    for r, (no, gid, _) in enumerate(maps):
+        for k in range(no):
+            p = int(phases[r][k])
+            keys.append((p if p >= 0 else 1 << 20, r, k))
+    order = sorted(range(len(keys)), key=lambda i: keys[i])
+    newpos = {(keys[i][1], keys[i][2]): pos for pos, i in enumerate(order)}
+    gid2new = {}
+    for r, (no, gid, _) in enumerate(maps):
+        for k in range(no):
+            gid2new[int(gid[k])] = newpos[(r, k)]
+    ntot = len(keys)
+    rows = [None] * ntot
+    flags_g = np.zeros(ntot, dtype=np.int32)
+    for r, la in enumerate(las):
+        no, gid, _ = maps[r]
+        for k in range(no):
+            sl = slice(la["rowptr"][k], la["rowptr"][k + 1])
+            cols = np.array([gid2new[int(gid[c])] for c in la["col"][sl]], dtype=np.int64)
+            o = np.argsort(cols, kind="stable")
+            rows[newpos[(r, k)]] = (cols[o], la["val"][sl][o])
+            flags_g[newpos[(r, k)]] = la["bcflags"][k]
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c, _ in rows])]).astype(np.int32)
+    bpts = np.flatnonzero(flags_g == 1).astype(np.int32)
+    rng = np.random.default_rng(11)
+    lag = dict(n=ntot, a_size=ntot, rowptr=rowptr, col=np.concatenate([c for c, _ in rows]).astype(np.int32),
+               val=np.concatenate([v for _, v in rows]), bcflags=flags_g, neumann=0, omega=1.4, iters=5,
+               btype=np.array([1], dtype=np.int32), bptr=np.array([0, len(bpts)], dtype=np.int32), bpts=bpts,
+               bvals=np.zeros(len(bpts)), x0=rng.standard_normal(ntot) * (flags_g == 0), b0=rng.standard_normal(ntot))
+    loc2new = [np.array([gid2new[int(v)] for v in gid]) for (_, gid, _) in maps]
+    for r, e in enumerate(emus):
+        no = maps[r][0]
+        e.x[:] = lag["x0"][loc2new[r]]
+        e.b[:] = 0.0
+        e.b[:no] = lag["b0"][loc2new[r][:no]]
+    nsweeps = 3
+    for _ in range(nsweeps):
+        for ph in range(gmax):
+            _exchange_vecs(emus, maps, lists, [e.x for e in emus])    # before EVERY phase
+            for e in emus:
+                e.sor_one_phase(ph)
+    o = H.oracle_level(lag)
+    o.sor_sweeps(nsweeps)
+    x = lag["x0"].copy()
+    for r, e in enumerate(emus):
+        x[loc2new[r][:maps[r][0]]] = e.x[:maps[r][0]]
+    assert H.rel_err(x, o.x) < 1e-12
+    # and the once-per-sweep schedule is a genuinely different iteration
+    for r, e in enumerate(emus):
+        e.x[:] = lag["x0"][loc2new[r]]
+    for _ in range(nsweeps):
+        _exchange_vecs(emus, maps, lists, [e.x for e in emus])
+        for e in emus:
+            e.sweeps(1)
+    xh = lag["x0"].copy()
+    for r, e in enumerate(emus):
+        xh[loc2new[r][:maps[r][0]]] = e.x[:maps[r][0]]
+    assert H.rel_err(xh, o.x) > 1e-6

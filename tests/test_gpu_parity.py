@@ -242,6 +242,70 @@ def test_rccl_ghost_exchange_single_rank_loopback():
         _capi.comm_finalize()
 
 
+def test_per_phase_exchange_mode_single_rank_loopback():
+    """mmg_level_set_exchange_mode(per_phase = 1) on one GPU with the rank as its own neighbour: the
+    collective phase check, the lock-step phase loop with an RCCL ghost refresh before every phase.
+    Expected iterates: the CPU interpreter of the same packed plan stepping phase by phase with manual
+    ghost copies (tests/test_distributed_cpu.py proves that schedule equal to the sequential oracle).
+    A ghost mapped to a point that its readers' phase also relaxes must be refused."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi, _host
+    pts, flags, gid, owner = _host.slab_cloud(0, 2, 12, dim=3, margin=5)
+    sub = _host.Grid.create_local(pts, flags, gid, owner, 3, 50, tile_points=256, lanes_per_row=2)
+    n_owned, lgid, gown = sub.local_map()
+    la = sub.level_arrays()
+    n_ghost = la["n"] - n_owned
+    rng = np.random.default_rng(9)
+    la["x0"] = rng.standard_normal(la["a_size"])
+    la["b0"] = rng.standard_normal(la["a_size"])
+    la["b0"][n_owned:] = 0.0
+    emu = H.EmuLevel(la, tile_ptr=sub.tile_ptr(), lanes_per_row=2, tile_phase=sub.tile_phase())
+    ph, gm = emu.point_phases()
+    nph = emu.info()["n_phases"]
+    assert nph >= 4
+    # a legal "neighbour": every ghost mirrors an owned interior point relaxed in a phase none of its readers runs in
+    by_phase = [np.flatnonzero(ph[:n_owned] == p) for p in range(nph)]
+    send_ok = np.zeros(n_ghost, dtype=np.int32)
+    send_bad = np.zeros(n_ghost, dtype=np.int32)
+    for j in range(n_ghost):
+        mask = int(gm[n_owned + j])
+        free = [p for p in range(nph) if not (mask >> p) & 1 and len(by_phase[p])]
+        used = [p for p in range(nph) if (mask >> p) & 1 and len(by_phase[p])]
+        send_ok[j] = rng.choice(by_phase[free[j % len(free)]])
+        send_bad[j] = rng.choice(by_phase[used[0]]) if used else send_ok[j]
+    assert any(int(gm[n_owned + j]) for j in range(n_ghost))
+
+    def make():
+        return _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], 0, 1.4, 5, la["btype"], la["bptr"],
+                           la["bpts"], la["bvals"], x=la["x0"], b=la["b0"], tile_ptr=sub.tile_ptr(), lanes_per_row=2,
+                           tile_phase=sub.tile_phase())
+
+    _capi.comm_init(0, 1, _capi.comm_unique_id())
+    try:
+        d = make()
+        assert np.array_equal(d.point_phases(), ph)
+        d.set_exchange(n_owned, [0], [0, n_ghost], send_bad, [0, n_ghost])
+        with pytest.raises(_capi.MmgError, match="no sequential order"):
+            d.set_exchange_mode(1)
+        d = make()
+        d.set_exchange(n_owned, [0], [0, n_ghost], send_ok, [0, n_ghost])
+        d.set_exchange_mode(1)
+        d.sweeps(3)
+        for _ in range(3):
+            for p in range(nph):
+                emu.x[n_owned:] = emu.x[send_ok]
+                emu.sor_one_phase(p)
+        xd = d.get_x()
+        assert H.rel_err(xd[:n_owned], emu.x[:n_owned]) < 1e-12
+        # the once-per-sweep schedule gives different iterates from the same state
+        h = make()
+        h.set_exchange(n_owned, [0], [0, n_ghost], send_ok, [0, n_ghost])
+        h.sweeps(3)
+        assert H.rel_err(h.get_x()[:n_owned], emu.x[:n_owned]) > 1e-8
+    finally:
+        _capi.comm_finalize()
+
+
 @pytest.mark.parametrize("name", ["dirichlet_3level", "neumann_3level"])
 @pytest.mark.parametrize("tile,L", [(64, 4), (32, 2), (200, 8)])
 def test_persistent_single_launch_sweep_matches_oracle(name, tile, L):
