@@ -23,10 +23,12 @@ def main():
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--polydeg", type=int, default=4)
     ap.add_argument("--persistent", type=int, default=1)
+    ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
     ap.add_argument("--oracle-cycles", type=int, default=0, help="also run this many cycles on the CPU oracle")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
     _capi.set_option("persistent_sweep", a.persistent)
+    _capi.set_option("lds_resident", a.lds_resident)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
     if a.dim == 3:

@@ -27,6 +27,12 @@ namespace {
 thread_local std::string g_err;
 thread_local std::vector<hipEvent_t> *g_sweep_events = nullptr;  // mmg_level_time_phases: event pair per sweep-kernel launch
 bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created afterwards use the exact kernels
+// mmg_set_option("slot_bits", 12 | 16): LDS-slot width of level plans created afterwards.  12-bit slots cut the
+// packed stream from 571 to 539 B/row at K = 50 but measured 4-5 % SLOWER in three alternating same-box A/B
+// pairs (1125/1071/1075 vs 1086/1024/1016 us per sweep at 1e7 points): the sweep is not purely byte-bound,
+// the straddling decode costs more than the bytes save.  Kept as an option, default 16.
+int g_slot_bits = 16;
+int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident tile streams for the phases of small levels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
@@ -180,8 +186,10 @@ struct PlanGpu {
         dev.stream = stream.p;
         dev.phase_tiles = phase_tiles.p;
         dev.L = P.L;
+        dev.slot_bits = P.slot_bits;
         dev.n_tiles = P.n_tiles;
         dev.lds_bytes = (unsigned)P.lds_bytes();
+        dev.lds_bytes_resident = (unsigned)std::min<size_t>(P.lds_bytes_resident(), 0xffffffffu);
         dev.max_plen = P.max_plen;
         return MMG_OK;
     }
@@ -190,6 +198,26 @@ struct PlanGpu {
 hipError_t run_tiles(const PlanGpu &pl, TileMode mode, const TileArgs &a, hipStream_t s)
 {
     return pl.exact ? launch_tile_kernel_exact(mode, a, s) : launch_tile_kernel(mode, a, s);
+}
+
+// One phase of a relaxation sweep.  Phases of at most a few tiles per CU (the coarse levels of a
+// V-cycle) are latency-bound -- one tile's dependency chain, ~28 groups x one global-load latency --
+// and run with the tile's whole packed stream resident in LDS instead (kernels.hip: tile_kernel_lds).
+hipError_t run_sor_phase(const PlanGpu &pl, const TileArgs &a, hipStream_t s)
+{
+    static int cus = 0, lds_cu = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
+            cus = p.multiProcessorCount;
+            lds_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+        } else cus = -1;
+    }
+    const bool small = g_lds_resident && !pl.exact && cus > 0 && (pl.dev.L == 2 || pl.dev.L == 4) &&
+                       pl.dev.lds_bytes_resident <= (unsigned)lds_cu && a.n_list <= (g_lds_resident > 1 ? g_lds_resident : 2) * cus;
+    if (small) return launch_tile_kernel_lds(a, s);
+    return run_tiles(pl, MODE_SOR, a, s);
 }
 
 int pick_L(int L) { return L > 0 ? L : 4; }
@@ -369,7 +397,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
             a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
             a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
             if ((erc = mark_event())) return erc;
-            HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
+            HIPC(run_sor_phase(lv->A, a, g_stream));
             if ((erc = mark_event())) return erc;
         }
     } else {
@@ -378,7 +406,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
             a.tile_list = lv->A.dev.phase_tiles + lv->A.phase_ptr[ph];
             a.n_list = lv->A.phase_ptr[ph + 1] - lv->A.phase_ptr[ph];
             if ((erc = mark_event())) return erc;
-            HIPC(run_tiles(lv->A, MODE_SOR, a, g_stream));
+            HIPC(run_sor_phase(lv->A, a, g_stream));
             if ((erc = mark_event())) return erc;
         }
     }
@@ -655,6 +683,8 @@ int mmg_set_option(const char *name, int value)
     if (!name) return fail(MMG_ERR_INVALID, "null option");
     if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value; return MMG_OK; }
     if (std::strcmp(name, "exact_arithmetic") == 0) { g_exact = value != 0; return MMG_OK; }
+    if (std::strcmp(name, "slot_bits") == 0) { g_slot_bits = value == 12 ? 12 : 16; return MMG_OK; }
+    if (std::strcmp(name, "lds_resident") == 0) { g_lds_resident = value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -779,7 +809,7 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
     {
         Plan P;
-        const std::string err = build_level_plan(*d, L, &P, g_exact);
+        const std::string err = build_level_plan(*d, L, &P, g_exact, g_slot_bits);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;
         if ((rc = lv->A.upload(P))) return rc;

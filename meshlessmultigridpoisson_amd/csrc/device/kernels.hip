@@ -9,6 +9,8 @@
 // inside a launch; Gauss-Seidel ordering between tiles is carried by the launch
 // order of the phases.  HBM-bound by construction: ~10 B per stored entry plus
 // ~34 B per row; no MFMA (irregular fp64 gather, 0.16 flop/B).
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace mmg {
@@ -45,17 +47,25 @@ __device__ __forceinline__ double row_sum(double v)
 }
 
 __device__ __forceinline__ size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+// 8-byte words of the slot section per lane (plan.hpp: slot_words)
+template <int BITS>
+__device__ __forceinline__ int slot_words_dev(int plen)
+{
+    return BITS == 12 ? (12 * plen + 63) >> 6 : (plen + 3) >> 2;
+}
+template <int BITS = 16>
 __device__ __forceinline__ size_t group_bytes_dev(int L, int nr, int plen)
 {
     const size_t W = (size_t)nr * L;
-    return (size_t)16 * nr + al16((size_t)plen * W * 8) + al16((size_t)((plen + 3) >> 2) * W * 8);
+    return (size_t)16 * nr + al16((size_t)plen * W * 8) + al16((size_t)slot_words_dev<BITS>(plen) * W * 8);
 }
 
 // Registers of one row group in flight: MAXP entries per lane.
-template <int MAXP>
+template <int MAXP, int BITS>
 struct GroupRegs {
+    static constexpr int NS = BITS == 12 ? (12 * MAXP + 63) / 64 : (MAXP + 3) / 4;
     double v[MAXP];
-    uint2 s[(MAXP + 3) / 4];
+    uint2 s[NS];
     RowMeta m;
     double d;
 };
@@ -63,27 +73,35 @@ struct GroupRegs {
 // Issue every global load of one group (no waits): the stream address depends on
 // nothing but the group heads, so the next group's loads fly while the current
 // group is gathered and reduced.
-template <int L, int MAXP>
-__device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int plen, int lane, GroupRegs<MAXP> &r)
+template <int L, int MAXP, int BITS, bool NT = true>
+__device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int plen, int lane, GroupRegs<MAXP, BITS> &r)
 {
     const int W = nr * L;
     // lanes beyond W re-read lane W-1's data (always in bounds); they are masked in finish()
     const int ln = lane < W ? lane : W - 1;
     const double *vals = reinterpret_cast<const double *>(p + 16 * nr) + ln;
     const uint2 *sl = reinterpret_cast<const uint2 *>(p + 16 * nr + al16((size_t)plen * W * 8)) + ln;
-    const int plen4 = (plen + 3) >> 2;
+    const int plen4 = slot_words_dev<BITS>(plen);
+    constexpr int NS = GroupRegs<MAXP, BITS>::NS;
 #ifndef MMG_PLAIN_STREAM  // non-temporal policy on the read-once matrix stream: +5 % at 1e7 points (L2/MALL keep the x halo lines)
+    if (!NT) {  // stream already resident in LDS (tile_kernel_lds): plain ds_reads
 #pragma unroll
-    for (int q4 = 0; q4 < (MAXP + 3) / 4; ++q4) {
+        for (int q4 = 0; q4 < NS; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
+    } else {
+#pragma unroll
+    for (int q4 = 0; q4 < NS; ++q4) {
         const unsigned long long w = __builtin_nontemporal_load(
             reinterpret_cast<const unsigned long long *>(sl + (q4 < plen4 ? q4 : plen4 - 1) * W));
         r.s[q4] = make_uint2((unsigned)(w & 0xffffffffull), (unsigned)(w >> 32));
     }
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) r.v[q] = __builtin_nontemporal_load(vals + (q < plen ? q : plen - 1) * W);
+    }
 #else
 #pragma unroll
-    for (int q4 = 0; q4 < (MAXP + 3) / 4; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
+    for (int q4 = 0; q4 < NS; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
 #endif
@@ -92,10 +110,21 @@ __device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int 
     r.d = reinterpret_cast<const double *>(p + 8 * nr)[rig];
 }
 
-__device__ __forceinline__ unsigned slot_of(const uint2 &s, int k)
+// LDS slot of entry q of the lane (q is a compile-time constant after unrolling)
+template <int BITS, int NS>
+__device__ __forceinline__ unsigned slot_at(const uint2 (&s)[NS], int q)
 {
-    const unsigned w = (k & 2) ? s.y : s.x;
-    return (k & 1) ? (w >> 16) : (w & 0xffffu);
+    if (BITS == 12) {
+        const int bit = 12 * q, w = bit >> 5, sh = bit & 31;
+        const unsigned lo = (w & 1) ? s[w >> 1].y : s[w >> 1].x;
+        if (sh <= 20) return (lo >> sh) & 0xfffu;
+        const int w1 = w + 1;
+        const unsigned hi = (w1 & 1) ? s[w1 >> 1].y : s[w1 >> 1].x;
+        return ((lo >> sh) | (hi << (32 - sh))) & 0xfffu;
+    }
+    const uint2 &u = s[q >> 2];
+    const unsigned w = (q & 2) ? u.y : u.x;
+    return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
 // x accesses of the dependency-driven sweep go through agent-scope relaxed atomics
@@ -116,7 +145,7 @@ __device__ __forceinline__ void st_x(double *p, double v)
 
 // One wavefront per tile.  LDS: xs[n_slots] (inputs) | bs[n_own] (rhs of the own
 // range, SOR/RESID) | gh[n_groups] (group heads).
-template <int L, int MODE, int MAXP, bool SC1>
+template <int L, int MODE, int MAXP, bool SC1, int BITS, bool LDSS = false>
 __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, unsigned char *smem, const double lam)
 {
     double *xs = reinterpret_cast<double *>(smem);
@@ -128,72 +157,109 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     double *bs = xs + n_slots;
     uint32_t *gh = reinterpret_cast<uint32_t *>(bs + (kUsesB ? n_own : 0));
 
+    // Small levels are latency-bound: a phase costs one tile's dependency chain.  LDSS pulls the tile's
+    // WHOLE packed stream into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, so every
+    // 1-KiB chunk is in flight at once instead of 8 loads per lane), default cache policy (a small
+    // level's matrix stays in L2/MALL from sweep to sweep); the groups then run at LDS latency.
+    const size_t lds_stream_off = ((size_t)(n_slots + (kUsesB ? n_own : 0)) * 8 + (size_t)n_groups * 4 + 15) & ~(size_t)15;
+    if constexpr (LDSS) {
+        const unsigned char *src = a.p.stream + td.stream_off;
+        const uint32_t n16 = td.stream_len >> 4;  // 16-byte units; the last chunk may be partial
+        for (uint32_t c = 0; c * 64 < n16; ++c) {
+            const uint32_t i = c * 64 + lane;
+            // lanes past the end re-read the last unit; their LDS bytes lie in the chunk's slack
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + (size_t)(i < n16 ? i : n16 - 1) * 16),
+                (__attribute__((address_space(3))) void *)(smem + lds_stream_off + (size_t)c * 1024), 16, 0, 0);
+        }
+    }
+
     // ---- stage inputs in LDS ------------------------------------------------
     const double *in = a.in;
     const uint32_t *ghg = a.p.ghead + td.ghead_off;
     for (uint32_t i = lane; i < n_groups; i += 64) gh[i] = ghg[i];
-    // batches of 8 independent loads per lane: one memory latency per batch
-    for (uint32_t base = 0; base < n_own; base += 512) {
-        double tx[8], tb[8];
+    // Two memory latencies for the whole input staging: the halo index list (first pass) is requested
+    // first and is in flight while the own range is staged in batches of 8 independent loads per lane;
+    // the halo values are then gathered with all the loads of a pass in flight at once.  Pass width: 512
+    // entries (L >= 4: 2-D tiles) or 2048 (L = 2: 3-D K = 50 tiles stage 1000-1500 halo values); same box,
+    // 1e7 points: 995/1000 us per sweep against 1024/1089 us with 512-entry passes after the own range.
+    const int32_t *hl = a.p.halo + td.halo_off;
+    auto stage = [&](auto hb_tag) {
+        constexpr int HB = decltype(hb_tag)::value;
+        int32_t ti[HB];
+        if (n_halo > 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + k * 64 + lane;
-            const uint32_t ii = i < n_own ? i : n_own - 1;
-            tx[k] = ld_x<SC1>(in + td.row0 + ii);
-#ifdef MMG_NT_AUX
-            if (kUsesB) tb[k] = __builtin_nontemporal_load(a.b + td.row0 + ii);
-#else
-            if (kUsesB) tb[k] = a.b[td.row0 + ii];
-#endif
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + k * 64 + lane;
-            if (i < n_own) {
-                xs[i] = tx[k];
-                if (kUsesB) bs[i] = tb[k];
+            for (int k = 0; k < HB; ++k) {
+                const uint32_t i = k * 64 + lane;
+                ti[k] = hl[i < n_halo ? i : n_halo - 1];
             }
         }
-    }
-    const int32_t *hl = a.p.halo + td.halo_off;
-    for (uint32_t base = 0; base < n_halo; base += 512) {
-        int32_t ti[8];
-        double tx[8];
+        for (uint32_t base = 0; base < n_own; base += 512) {
+            double tx[8], tb[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + k * 64 + lane;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * 64 + lane;
+                const uint32_t ii = i < n_own ? i : n_own - 1;
+                tx[k] = ld_x<SC1>(in + td.row0 + ii);
 #ifdef MMG_NT_AUX
-            ti[k] = __builtin_nontemporal_load(hl + (i < n_halo ? i : n_halo - 1));
+                if (kUsesB) tb[k] = __builtin_nontemporal_load(a.b + td.row0 + ii);
 #else
-            ti[k] = hl[i < n_halo ? i : n_halo - 1];
+                if (kUsesB) tb[k] = a.b[td.row0 + ii];
 #endif
-        }
+            }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tx[k] = ld_x<SC1>(in + ti[k]);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t i = base + k * 64 + lane;
-            if (i < n_halo) xs[n_own + i] = tx[k];
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t i = base + k * 64 + lane;
+                if (i < n_own) {
+                    xs[i] = tx[k];
+                    if (kUsesB) bs[i] = tb[k];
+                }
+            }
         }
-    }
+        for (uint32_t base = 0; base < n_halo; base += 64 * HB) {
+            if (base > 0) {
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const uint32_t i = base + k * 64 + lane;
+                    ti[k] = hl[i < n_halo ? i : n_halo - 1];
+                }
+            }
+            double tx[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) tx[k] = ld_x<SC1>(in + ti[k]);
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const uint32_t i = base + k * 64 + lane;
+                if (i < n_halo) xs[n_own + i] = tx[k];
+            }
+        }
+    };
+    // one width per kernel (no second code path: its registers would cost the L >= 4 kernels occupancy --
+    // measured 9 % on the 2-D V-cycle): 2-lane rows are the 3-D K = 50 stencils with 1000-1500 halo values
+    stage(std::integral_constant<int, (L <= 2 ? 32 : 8)>{});
     if (lane == 0) xs[n_slots - 1] = 0.0;
 
     const unsigned char *p = a.p.stream + td.stream_off;
-    GroupRegs<MAXP> ra, rb;
+    if constexpr (LDSS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA copy of the stream has landed
+        __syncthreads();
+        p = smem + lds_stream_off;
+    }
+    GroupRegs<MAXP, BITS> ra, rb;
     uint32_t h_cur = n_groups ? ghg[0] : 0;  // first head straight from global: no LDS round trip
-    if (n_groups) issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+    if (n_groups) issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
     __syncthreads();
 
     const int sub = lane & (L - 1);
     double local = 0.0;  // RESID: sum |r|
 
-    auto finish = [&](const GroupRegs<MAXP> &r, int nr, int plen) {
+    auto finish = [&](const GroupRegs<MAXP, BITS> &r, int nr, int plen) {
         const int W = nr * L;
         double acc = 0.0;
 #pragma unroll
         for (int q = 0; q < MAXP; ++q) {
             const double v = (q < plen && lane < W) ? r.v[q] : 0.0;
-            acc = fma(v, xs[slot_of(r.s[q >> 2], q & 3)], acc);
+            acc = fma(v, xs[slot_at<BITS>(r.s, q)], acc);
         }
         acc = row_sum<L>(acc);
         if (lane < W && sub == 0) {
@@ -231,19 +297,19 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 #ifndef MMG_UNCOND_ISSUE  // default: prefetch only when a next group exists (A/B: +3 % at 1e7 points, -4 % on small levels)
     for (uint32_t g = 0; g < n_groups; g += 2) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
-        const unsigned char *p1 = p + group_bytes_dev(L, nr0, pl0);
+        const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
         uint32_t h1 = 0;
         if (g + 1 < n_groups) {
             h1 = gh[g + 1];
-            issue_group<L, MAXP>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
+            issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
         }
         finish(ra, nr0, pl0);
         if (g + 1 >= n_groups) break;
         const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
-        p = p1 + group_bytes_dev(L, nr1, pl1);
+        p = p1 + group_bytes_dev<BITS>(L, nr1, pl1);
         if (g + 2 < n_groups) {
             h_cur = gh[g + 2];
-            issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+            issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
         }
         finish(rb, nr1, pl1);
     }
@@ -251,16 +317,16 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     for (uint32_t g = 0; g < n_groups; g += 2) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
         const bool has1 = g + 1 < n_groups;
-        const unsigned char *p1 = has1 ? p + group_bytes_dev(L, nr0, pl0) : p;
+        const unsigned char *p1 = has1 ? p + group_bytes_dev<BITS>(L, nr0, pl0) : p;
         const uint32_t h1 = has1 ? gh[g + 1] : h_cur;
-        issue_group<L, MAXP>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
+        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
         finish(ra, nr0, pl0);
         if (!has1) break;
         const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
         const bool has2 = g + 2 < n_groups;
-        p = has2 ? p1 + group_bytes_dev(L, nr1, pl1) : p1;
+        p = has2 ? p1 + group_bytes_dev<BITS>(L, nr1, pl1) : p1;
         h_cur = has2 ? gh[g + 2] : h1;
-        issue_group<L, MAXP>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+        issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
         finish(rb, nr1, pl1);
     }
 
@@ -292,7 +358,7 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     }
 }
 
-template <int L, int MODE, int MAXP>
+template <int L, int MODE, int MAXP, int BITS>
 __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -306,7 +372,21 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
     double lam = 0.0;
     if (MODE == MODE_SOR || MODE == MODE_RESID)
         if (a.lambda) lam = *a.lambda;
-    process_tile<L, MODE, MAXP, false>(a, tile, smem, lam);
+    process_tile<L, MODE, MAXP, false, BITS>(a, tile, smem, lam);
+}
+
+// Latency-optimised sweep phase for SMALL levels (at most a few tiles per CU): one workgroup per
+// tile with the tile's packed stream resident in LDS (up to the CU's whole 160 KiB), see process_tile.
+template <int L, int MAXP, int BITS>
+__global__ __launch_bounds__(64) void tile_kernel_lds(TileArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int idx = (int)blockIdx.x;
+    if (idx >= a.n_list) return;
+    const int tile = a.tile_list ? a.tile_list[idx] : idx;
+    double lam = 0.0;
+    if (a.lambda) lam = *a.lambda;
+    process_tile<L, MODE_SOR, MAXP, false, BITS, true>(a, tile, smem, lam);
 }
 
 // Dependency-driven sweep: ONE launch per sweep.  Resident wavefronts draw tiles from a
@@ -317,7 +397,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
 // running -- no co-residency requirement, no grid barrier.  Visibility: x is written with
 // sc1 stores, drained (vmcnt(0)), released at agent scope, then the tile's flag is stored;
 // the consumer polls relaxed, acquires once at agent scope, and reads x with sc1 loads.
-template <int L, int MAXP, bool FENCE>
+template <int L, int MAXP, bool FENCE, int BITS>
 __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -363,7 +443,7 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        process_tile<L, MODE_SOR, MAXP, true>(a, tile, smem, lam);
+        process_tile<L, MODE_SOR, MAXP, true, BITS>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FENCE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -374,18 +454,31 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
     }
 }
 
+// 12-bit slot streams exist for level plans only (SOR / RESID, L = 2 or 4: level_plan.cpp)
+template <int L>
+constexpr bool kHas12 = (L == 2 || L == 4);
+
 template <int L, int MAXP>
 hipError_t launch_LP(TileMode mode, const TileArgs &a, hipStream_t s)
 {
     const int per = (a.n_list + 7) / 8;
     const dim3 grid((unsigned)(per * 8)), block(64);
     const size_t lds = a.p.lds_bytes;
+    if (a.p.slot_bits == 12) {
+        if constexpr (kHas12<L>) {
+            if (mode == MODE_SOR) hipLaunchKernelGGL((tile_kernel<L, MODE_SOR, MAXP, 12>), grid, block, lds, s, a);
+            else if (mode == MODE_RESID) hipLaunchKernelGGL((tile_kernel<L, MODE_RESID, MAXP, 12>), grid, block, lds, s, a);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     switch (mode) {
-    case MODE_SOR: hipLaunchKernelGGL((tile_kernel<L, MODE_SOR, MAXP>), grid, block, lds, s, a); break;
-    case MODE_BOUND: hipLaunchKernelGGL((tile_kernel<L, MODE_BOUND, MAXP>), grid, block, lds, s, a); break;
-    case MODE_RESID: hipLaunchKernelGGL((tile_kernel<L, MODE_RESID, MAXP>), grid, block, lds, s, a); break;
-    case MODE_SET: hipLaunchKernelGGL((tile_kernel<L, MODE_SET, MAXP>), grid, block, lds, s, a); break;
-    case MODE_ADD: hipLaunchKernelGGL((tile_kernel<L, MODE_ADD, MAXP>), grid, block, lds, s, a); break;
+    case MODE_SOR: hipLaunchKernelGGL((tile_kernel<L, MODE_SOR, MAXP, 16>), grid, block, lds, s, a); break;
+    case MODE_BOUND: hipLaunchKernelGGL((tile_kernel<L, MODE_BOUND, MAXP, 16>), grid, block, lds, s, a); break;
+    case MODE_RESID: hipLaunchKernelGGL((tile_kernel<L, MODE_RESID, MAXP, 16>), grid, block, lds, s, a); break;
+    case MODE_SET: hipLaunchKernelGGL((tile_kernel<L, MODE_SET, MAXP, 16>), grid, block, lds, s, a); break;
+    case MODE_ADD: hipLaunchKernelGGL((tile_kernel<L, MODE_ADD, MAXP, 16>), grid, block, lds, s, a); break;
     }
     return hipGetLastError();
 }
@@ -405,10 +498,17 @@ hipError_t launch_L(TileMode mode, const TileArgs &a, hipStream_t s)
 template <int L, int MAXP>
 hipError_t launch_persist_LP(const TileArgs &a, int workers, hipStream_t s)
 {
-    if (a.fence)
-        hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, true>), dim3((unsigned)workers), dim3(64), a.p.lds_bytes, s, a);
-    else
-        hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, false>), dim3((unsigned)workers), dim3(64), a.p.lds_bytes, s, a);
+    const dim3 grid((unsigned)workers), block(64);
+    if (a.p.slot_bits == 12) {
+        if constexpr (kHas12<L>) {
+            if (a.fence) hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, true, 12>), grid, block, a.p.lds_bytes, s, a);
+            else hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, false, 12>), grid, block, a.p.lds_bytes, s, a);
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
+    if (a.fence) hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, true, 16>), grid, block, a.p.lds_bytes, s, a);
+    else hipLaunchKernelGGL((sweep_persistent_kernel<L, MAXP, false, 16>), grid, block, a.p.lds_bytes, s, a);
     return hipGetLastError();
 }
 template <int L>
@@ -780,14 +880,56 @@ hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+template <int L, int MAXP, int BITS>
+hipError_t launch_lds_LPB(const TileArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel_lds<L, MAXP, BITS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tile_kernel_lds<L, MAXP, BITS>), dim3((unsigned)a.n_list), dim3(64), a.p.lds_bytes_resident, s, a);
+    return hipGetLastError();
+}
+template <int L, int BITS>
+hipError_t launch_lds_LB(const TileArgs &a, hipStream_t s)
+{
+    const int mp = a.p.max_plen;
+    if (mp <= 8) return launch_lds_LPB<L, 8, BITS>(a, s);
+    if (mp <= 16) return launch_lds_LPB<L, 16, BITS>(a, s);
+    if (mp <= 28) return launch_lds_LPB<L, 28, BITS>(a, s);
+    if (mp <= 64) return launch_lds_LPB<L, 64, BITS>(a, s);
+    return hipErrorInvalidValue;
+}
+// SOR phase of a small level, L = 2 or 4 only (the lanes-per-row values level plans pick)
+hipError_t launch_tile_kernel_lds(const TileArgs &a, hipStream_t s)
+{
+    if (a.n_list <= 0) return hipSuccess;
+    const bool b12 = a.p.slot_bits == 12;
+    if (a.p.L == 2) return b12 ? launch_lds_LB<2, 12>(a, s) : launch_lds_LB<2, 16>(a, s);
+    if (a.p.L == 4) return b12 ? launch_lds_LB<4, 12>(a, s) : launch_lds_LB<4, 16>(a, s);
+    return hipErrorInvalidValue;
+}
+
+template <int L, int BITS>
+hipError_t occ_LB(const PlanDev &p, int *blocks)
+{
+    const int mp = p.max_plen;
+    if (mp <= 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 8, false, BITS>, 64, p.lds_bytes);
+    if (mp <= 16) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 16, false, BITS>, 64, p.lds_bytes);
+    if (mp <= 28) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 28, false, BITS>, 64, p.lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 64, false, BITS>, 64, p.lds_bytes);
+}
 template <int L>
 hipError_t occ_L(const PlanDev &p, int *blocks)
 {
-    const int mp = p.max_plen;
-    if (mp <= 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 8, false>, 64, p.lds_bytes);
-    if (mp <= 16) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 16, false>, 64, p.lds_bytes);
-    if (mp <= 28) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 28, false>, 64, p.lds_bytes);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, sweep_persistent_kernel<L, 64, false>, 64, p.lds_bytes);
+    if (p.slot_bits == 12) {
+        if constexpr (kHas12<L>) return occ_LB<L, 12>(p, blocks);
+        return hipErrorInvalidValue;
+    }
+    return occ_LB<L, 16>(p, blocks);
 }
 
 hipError_t sweep_persistent_blocks_per_cu(const PlanDev &p, int *blocks)

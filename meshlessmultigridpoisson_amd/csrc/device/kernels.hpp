@@ -13,8 +13,10 @@ struct PlanDev {
     const uint8_t *stream = nullptr;
     const int32_t *phase_tiles = nullptr;
     int L = 4;
+    int slot_bits = 16;  // Plan::slot_bits
     int n_tiles = 0;
     unsigned lds_bytes = 0;
+    unsigned lds_bytes_resident = 0;  // Plan::lds_bytes_resident(): + one tile's whole stream (tile_kernel_lds)
     int max_plen = 0;
     const int32_t *dep_ptr = nullptr;  // in-place plans
     const int32_t *dep_idx = nullptr;
@@ -52,6 +54,9 @@ struct TileArgs {
 };
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
+// SOR phase with the tile's packed stream resident in LDS: one workgroup per tile, for phases of at
+// most a few tiles per CU (latency-bound small levels).  L = 2 / 4 plans with lds_bytes_resident <= LDS per CU.
+hipError_t launch_tile_kernel_lds(const TileArgs &a, hipStream_t s);
 // exact-arithmetic variant (plans built with exact = true, L = 1): every row is accumulated by
 // one lane in the reference's stored order with separately rounded multiply and add
 hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_t s);

@@ -44,7 +44,7 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
     return err;
 }
 
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact)
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits)
 {
     const int n = d.n;
     CsrView A{d.a_size, d.a_size, d.rowptr, d.col, d.val};
@@ -95,7 +95,12 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         s.exact = exact;
         // hints index the caller's tiles: dropped once tiles had to be split
         s.tile_phase_hint = (attempt == 0 && d.tile_ptr && d.n_tiles > 0) ? d.tile_phase : nullptr;
+        s.slot_bits = (slot_bits == 12 && !exact && (L == 2 || L == 4)) ? 12 : 16;
         err = build_plan(s, out);
+        if (err.rfind("slots-exceed-12-bit", 0) == 0) {  // a tile stages more than 4096 values: 16-bit slots
+            s.slot_bits = 16;
+            err = build_plan(s, out);
+        }
         if (err.empty() || err.rfind("tile-too-large", 0) != 0) return err;
         std::vector<int32_t> split;  // halve every tile and retry
         for (int t = 0; t < nt; ++t) {

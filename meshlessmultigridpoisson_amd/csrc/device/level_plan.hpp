@@ -17,7 +17,8 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
 
 // Plan A of a level: interior rows (bcflags == 0) in storage order, own range of
 // a tile == its points.  Tile boundaries come from desc.tile_ptr or tile_size.
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false);
+// slot_bits 12: packed 12-bit LDS slots where possible (L = 2 or 4, every tile <= 4096 slots), else 16.
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false, int slot_bits = 16);
 
 // Domain decomposition, exact (per-phase) ghost exchange: phase[i] = phase of the sweep in which
 // point i is relaxed by plan A (-1: never relaxed); ghost_mask[j] (ghost points, bcflags == 3) = bit

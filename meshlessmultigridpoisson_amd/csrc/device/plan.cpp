@@ -96,6 +96,11 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         cleanup();
         return;
     }
+    if (s.slot_bits == 12 && n_slots > 4096) {
+        tb.err = "slots-exceed-12-bit: " + std::to_string(n_slots) + " LDS slots";
+        cleanup();
+        return;
+    }
     const uint16_t zero_slot = (uint16_t)(n_slots - 1);
     auto slot = [&](int32_t col) -> uint16_t {
         if (col >= lo && col < hi) return (uint16_t)(col - lo);
@@ -173,7 +178,17 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             const size_t base = tb.blob.size();
             const size_t vals_off = base + (size_t)16 * g;
             const size_t slots_off = vals_off + align16((size_t)plen * W * 8);
-            tb.blob.resize(base + group_bytes(L, g, plen), 0);
+            tb.blob.resize(base + group_bytes(L, g, plen, s.slot_bits), 0);
+            // 12-bit stream: slot q of a lane = bits [12q, 12q+12) of its words (word w at [w*W + lane])
+            auto put12 = [&](uint8_t *Bp, size_t q, size_t lane, uint16_t v) {
+                for (int b = 0; b < 12; ++b) {
+                    const size_t bit = 12 * q + (size_t)b;
+                    uint8_t *byte = Bp + slots_off + ((bit / 64) * W + lane) * 8 + (bit % 64) / 8;
+                    const uint8_t m = (uint8_t)(1u << (bit % 8));
+                    if ((v >> b) & 1) *byte |= m;
+                    else *byte &= (uint8_t)~m;
+                }
+            };
             uint8_t *B = tb.blob.data();
             for (int i = 0; i < g; ++i) {
                 const int k = rows[g0 + i];
@@ -181,6 +196,10 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                 std::memcpy(B + base + (size_t)8 * g + (size_t)8 * i, &diag[k], 8);
             }
             // fill everything with padding first
+            if (s.slot_bits == 12) {
+                for (size_t q = 0; q < (size_t)plen; ++q)
+                    for (size_t lane = 0; lane < W; ++lane) put12(B, q, lane, zero_slot);
+            } else
             for (size_t q = 0; q < plen4 * 4; ++q)
                 for (size_t lane = 0; lane < W; ++lane) {
                     const size_t si = ((q / 4) * W + lane) * 4 + (q % 4);
@@ -192,6 +211,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     const size_t q = x / L, sub = x % L;
                     const size_t lane = (size_t)i * L + sub;
                     std::memcpy(B + vals_off + (q * W + lane) * 8, &e[x].val, 8);
+                    if (s.slot_bits == 12) { put12(B, q, lane, e[x].slot); continue; }
                     const size_t si = ((q / 4) * W + lane) * 4 + (q % 4);
                     std::memcpy(B + slots_off + si * 2, &e[x].slot, 2);
                 }
@@ -257,6 +277,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     Plan &P = *out;
     P = Plan();
     P.L = L;
+    P.slot_bits = s.slot_bits == 12 ? 12 : 16;
     P.n_tiles = s.n_tiles;
     P.tiles.resize(s.n_tiles);
     size_t stream_sz = 0, halo_sz = 0, gh_sz = 0;
@@ -271,6 +292,8 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         d.n_halo = (uint32_t)tb[t].halo.size();
         d.n_groups = (uint32_t)tb[t].ghead.size();
         d.n_rows = (uint32_t)(s.tile_ptr[t + 1] - s.tile_ptr[t]);
+        d.stream_len = (uint32_t)tb[t].blob.size();
+        P.max_stream = std::max(P.max_stream, tb[t].blob.size());
         stream_sz += tb[t].blob.size();
         halo_sz += tb[t].halo.size();
         gh_sz += tb[t].ghead.size();

@@ -19,6 +19,7 @@
 //   double   diag[g]
 //   double   val [plen*W]       val [q*W + lane]
 //   uint16   slot[plen4*W*4]    slot[((q/4)*W + lane)*4 + q%4]  (plen4=ceil(plen/4))
+//            (Plan::slot_bits == 12: 12-bit slots, see slot_words())
 // lane = row_in_group*L + sub; entry e of a row sits at q = e/L, sub = e%L.
 // `slot` is the tile-local LDS slot of the entry's column (16 bit: a stored
 // entry costs 10 B instead of CSR's 12 B).  Padding entries carry val = 0 and
@@ -46,7 +47,8 @@ struct TileDesc {          // 48 bytes, read by the kernels with scalar loads
     uint32_t n_groups;
     uint32_t ghead_off;    // into Plan::ghead
     uint32_t n_rows;       // rows handled by the tile
-    uint32_t pad0, pad1;
+    uint32_t stream_len;   // bytes of the tile's packed groups (multiple of 16)
+    uint32_t pad1;
 };
 static_assert(sizeof(TileDesc) == 48, "TileDesc layout");
 
@@ -63,16 +65,23 @@ constexpr int kMaxSlots = 7680;  // (slots + own rhs) * 8 B + group heads must f
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
+// slot section of one group: per lane either ceil(plen/4) 8-byte words of four 16-bit slots, or
+// (slot_bits == 12) a little-endian bit stream of plen 12-bit slots in ceil(12*plen/64) 8-byte
+// words -- 37.5 instead of 56 B per lane at plen = 25; word w of lane l sits at [w*W + l].
+inline size_t slot_words(int bits, int plen)
+{
+    return bits == 12 ? ((size_t)12 * plen + 63) / 64 : ((size_t)plen + 3) / 4;
+}
 // byte size of one packed group
-inline size_t group_bytes(int L, int g, int plen)
+inline size_t group_bytes(int L, int g, int plen, int bits = 16)
 {
     const size_t W = (size_t)g * L;
-    const size_t plen4 = ((size_t)plen + 3) / 4;
-    return (size_t)16 * g + align16((size_t)plen * W * 8) + align16(plen4 * W * 8);
+    return (size_t)16 * g + align16((size_t)plen * W * 8) + align16(slot_words(bits, plen) * W * 8);
 }
 
 struct Plan {
     int L = 4;                         // lanes per row
+    int slot_bits = 16;                // 16, or 12 when every tile has <= 4096 LDS slots (level plans, L = 2/4)
     int n_tiles = 0;
     std::vector<TileDesc> tiles;
     std::vector<int32_t> halo;         // input indices staged after the own range
@@ -90,11 +99,15 @@ struct Plan {
     int max_groups = 0;                // max groups of one tile
     int max_own = 0;                   // max own range of one tile (b is staged next to x)
     int max_plen = 0;                  // max entries per lane of one group
+    size_t max_stream = 0;             // largest stream_len of a tile (LDS-resident small-level kernel)
     long long n_rows = 0;              // rows in the plan
     long long n_nnz = 0;               // stored (non-padding) entries
     long long n_groups = 0;
     int n_phases() const { return (int)phase_ptr.size() - 1; }
     size_t lds_bytes() const { return ((size_t)max_slots + (size_t)max_own) * 8 + (size_t)max_groups * 4; }
+    // the same plus room for one tile's whole packed stream (tile_kernel_lds)
+    // (copied in 1-KiB LDS-DMA chunks: the last one may overhang by < 1 KiB)
+    size_t lds_bytes_resident() const { return align16(lds_bytes()) + ((max_stream + 1023) & ~(size_t)1023) + 16; }
 };
 
 struct PlanSpec {
@@ -121,6 +134,7 @@ struct PlanSpec {
     // tile colours of the GLOBAL colouring, so that all ranks number their phases alike
     // (mmg_level_set_exchange_mode); any value >= the dependency-derived phase keeps the schedule exact.
     const int32_t *tile_phase_hint = nullptr;
+    int slot_bits = 16;         // 12: fails with "slots-exceed-12-bit" if a tile stages more than 4096 values
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).

@@ -58,7 +58,18 @@ void run_tile(const Plan &P, int tile, int mode, const double *in, double *out, 
             for (int sub = 0; sub < L; ++sub) {
                 const int lane = r * L + sub;
                 for (int q = 0; q < plen; ++q) {
-                    const uint16_t s = sl[(((size_t)(q / 4)) * W + lane) * 4 + (q % 4)];
+                    uint16_t s;
+                    if (P.slot_bits == 12) {  // bits [12q, 12q+12) of the lane's little-endian word stream
+                        const uint8_t *sb = reinterpret_cast<const uint8_t *>(sl);
+                        unsigned v = 0;
+                        for (int bb = 0; bb < 12; ++bb) {
+                            const size_t bit = (size_t)12 * q + bb;
+                            const uint8_t byte = sb[((bit / 64) * W + lane) * 8 + (bit % 64) / 8];
+                            v |= (unsigned)((byte >> (bit % 8)) & 1) << bb;
+                        }
+                        s = (uint16_t)v;
+                    } else
+                    s = sl[(((size_t)(q / 4)) * W + lane) * 4 + (q % 4)];
                     lane_acc[sub] = std::fma(vals[(size_t)q * W + lane], xs[s], lane_acc[sub]);
                 }
             }
@@ -90,7 +101,7 @@ void run_tile(const Plan &P, int tile, int mode, const double *in, double *out, 
                 out[m.gid] += acc[r];
             }
         }
-        p += group_bytes(L, nr, plen);
+        p += group_bytes(L, nr, plen, P.slot_bits);
         (void)plen4;
     }
     if (mode == M_SOR)
@@ -118,9 +129,13 @@ void run_plan(const Plan &P, int mode, double *x_inout, const double *in_other, 
 
 }  // namespace
 
+int g_slot_bits = 16;  // like libmmgp's default (mmg_set_option "slot_bits")
+
 extern "C" {
 
 const char *emu_last_error() { return g_err.c_str(); }
+void emu_set_slot_bits(int bits) { g_slot_bits = bits == 12 ? 12 : 16; }
+int emu_level_slot_bits(void *h);
 
 void *emu_level_create(const mmg_level_desc *d)
 {
@@ -131,7 +146,7 @@ void *emu_level_create(const mmg_level_desc *d)
     const int L = d->lanes_per_row > 0 ? d->lanes_per_row : 4;
     std::string err = check_multiplier(*d);
     if (err.empty()) err = build_boundary_lists(*d, &e->bl);
-    if (err.empty()) err = build_level_plan(*d, L, &e->A);
+    if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits);
     if (err.empty() && !e->bl.neu_rows.empty()) {
         CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
         err = build_gather_plan_host(A, e->bl.neu_rows, L, 64, true, true, true, -1, &e->B);
@@ -154,6 +169,7 @@ void emu_level_info(void *h, int *out6)
     out6[5] = e->B.n_rows ? e->B.n_phases() : 0;
 }
 
+int emu_level_slot_bits(void *h) { return static_cast<Emu *>(h)->A.slot_bits; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
 

@@ -359,6 +359,70 @@ def test_persistent_sweep_3d_many_tiles():
         _capi.set_option("persistent_sweep", 1)
 
 
+@pytest.mark.parametrize("name,tile,L", [("dirichlet_3level", 64, 4), ("neumann_3level", 48, 2), ("neumann_3level", 200, 4)])
+def test_lds_resident_phase_kernel_and_12bit_slots_change_no_bit(name, tile, L):
+    """Two layout/latency options of the sweep: (i) small levels run their phases with the tile's whole packed
+    stream resident in LDS (tile_kernel_lds, default on), (ii) mmg_set_option("slot_bits", 12) packs the
+    tile-local column indices in 12 bits.  Neither changes the order of any floating-point operation:
+    iterates are bitwise those of the plain per-phase kernel with 16-bit slots, and follow the oracle."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    la = H.level_arrays(case, case["nlevels"] - 1)
+    o = H.oracle_level(la)
+    o.boundary_op(0)
+    o.sor_sweeps(3)
+    xs = {}
+    try:
+        for key, (res, bits) in {"plain": (0, 16), "lds": (1, 16), "lds12": (1, 12), "plain12": (0, 12)}.items():
+            _capi.set_option("lds_resident", res)
+            _capi.set_option("slot_bits", bits)
+            _capi.set_option("persistent_sweep", 0)
+            d = H.device_level(la, tile_size=tile, lanes_per_row=L)
+            d.boundary_op(0)
+            d.sweeps(3)
+            xs[key] = d.get_x()
+            assert H.rel_err(xs[key], o.x) < 1e-12, key
+            assert abs(d.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio(), key
+    finally:
+        _capi.set_option("lds_resident", 1)
+        _capi.set_option("slot_bits", 16)
+        _capi.set_option("persistent_sweep", 1)
+    for key in ("lds", "lds12", "plain12"):
+        assert np.array_equal(xs[key], xs["plain"]), key
+
+
+def test_lds_resident_phase_kernel_3d_k50():
+    """The same on the 3-D K = 50 stencils of the coarse V-cycle levels (135 KB of stream per 256-point tile,
+    more than 64 KiB of dynamic LDS per workgroup), including the single-launch sweep with 12-bit slots."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi, _host
+    pts = _host.box_cloud(30, 3, seed=4)
+    g = _host.Grid.create_square(pts, 3, dim=3, kind=_host.KIND_GRAPH, ordering=_host.ORDER_MC, tile_points=256,
+                                 lanes_per_row=2)
+    la = g.level_arrays()
+    la["b0"] = np.random.default_rng(3).standard_normal(la["a_size"])
+    o = H.oracle_level(la)
+    o.sor_sweeps(3)
+    xs = {}
+    try:
+        for key, (res, bits, pers) in {"plain": (0, 16, 0), "lds": (1, 16, 0), "lds12": (1, 12, 0), "single12": (0, 12, 4)}.items():
+            _capi.set_option("lds_resident", res)
+            _capi.set_option("slot_bits", bits)
+            _capi.set_option("persistent_sweep", pers)
+            d = _capi.Level(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], 0, 1.4, 5, la["btype"], la["bptr"],
+                            la["bpts"], la["bvals"], x=la["x0"], b=la["b0"], tile_ptr=g.tile_ptr(), lanes_per_row=2)
+            d.sweeps(3)
+            xs[key] = d.get_x()
+            assert H.rel_err(xs[key], o.x) < 1e-12, key
+    finally:
+        _capi.set_option("lds_resident", 1)
+        _capi.set_option("slot_bits", 16)
+        _capi.set_option("persistent_sweep", 1)
+    for key in ("lds", "lds12", "single12"):
+        assert np.array_equal(xs[key], xs["plain"]), key
+
+
 @pytest.fixture
 def exact_mode():
     from meshlessmultigridpoisson_amd import _capi
