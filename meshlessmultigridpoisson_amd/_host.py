@@ -76,6 +76,9 @@ def lib():
         L.mmgh_write_vector_txt.argtypes = [_dp, C.c_int, C.c_char_p]
         L.mmgh_order_from_txt.argtypes = [C.c_char_p, C.c_int]
         L.mmgh_write_msh.argtypes = [C.c_char_p, _dp, C.c_int]
+        L.mmgh_write_bin.argtypes = [C.c_char_p, _dp, C.c_int, C.c_int]
+        L.mmgh_points_from_bin.argtypes = [C.c_char_p, _dp, C.c_longlong, _ip]
+        L.mmgh_points_from_bin.restype = C.c_longlong
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_fs_create_square.restype = vp
         L.mmgh_fs_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
@@ -108,6 +111,24 @@ def set_option(name, value):
     """mmgh_set_option: "device_setup" -1 automatic / 0 host threads / 1 batched dense solves on the MI355X."""
     if lib().mmgh_set_option(name.encode(), int(value)) != 0:
         raise HostError(_err())
+
+
+def write_cloud_bin(fname, points, dim):
+    """Binary point-cloud container (fileReadingFunctions.h: writePointsToBinFile)."""
+    pts = _d(points).reshape(-1, 3)
+    if lib().mmgh_write_bin(os.fsencode(fname), pts.ctypes.data_as(_dp), len(pts), int(dim)) != 0:
+        raise HostError(f"cannot write {fname}")
+
+
+def read_cloud_bin(fname):
+    """-> (points[n, 3], dim); raises on a missing / foreign / truncated file."""
+    d = C.c_int(0)
+    n = lib().mmgh_points_from_bin(os.fsencode(fname), None, 0, C.byref(d))
+    if n <= 0:
+        raise HostError(f"{fname}: not a readable MMGCLOUD file")
+    xyz = np.zeros((n, 3))
+    lib().mmgh_points_from_bin(os.fsencode(fname), xyz.ctypes.data_as(_dp), n, C.byref(d))
+    return xyz, d.value
 
 
 def stencil_size(polydeg, dim=2):

@@ -105,6 +105,15 @@ __device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int 
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
 #endif
+    if (BITS == 12) {
+        // Entries q >= plen are masked by their value (0), but their slot must still be a valid LDS index:
+        // 0 * (whatever lies beyond the tile's slots) may be NaN.  With 16-bit slots a re-read word holds
+        // valid slots; a 12-bit window over re-read words does not, so words past the group's own are zeroed
+        // (slot 0; bits past 12*plen inside the last own word are zero in the packed stream).
+#pragma unroll
+        for (int q4 = 0; q4 < NS; ++q4)
+            if (q4 >= plen4) r.s[q4] = make_uint2(0u, 0u);
+    }
     const int rig = ln / L;
     r.m = reinterpret_cast<const RowMeta *>(p)[rig];
     r.d = reinterpret_cast<const double *>(p + 8 * nr)[rig];

@@ -1,5 +1,6 @@
 #include "fileReadingFunctions.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -134,4 +135,76 @@ bool writePointsToMshFile(const char *fname, const std::vector<std::tuple<double
     }
     std::fclose(f);
     return true;
+}
+
+// ---- binary cloud container (not in the reference; fileReadingFunctions.h) ------------------
+namespace {
+struct BinHeader {
+    char magic[8];
+    unsigned int version, dim;
+    unsigned long long n;
+};
+static_assert(sizeof(BinHeader) == 24, "binary cloud header layout");
+const char kBinMagic[8] = {'M', 'M', 'G', 'C', 'L', 'O', 'U', 'D'};
+}  // namespace
+
+bool writePointsToBinFile(const char *fname, const std::vector<std::tuple<double, double, double>> &pts, int dim)
+{
+    FILE *f = std::fopen(fname, "wb");
+    if (!f) return false;
+    BinHeader h;
+    std::memcpy(h.magic, kBinMagic, 8);
+    h.version = 1;
+    h.dim = (unsigned)dim;
+    h.n = pts.size();
+    bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1;
+    std::vector<double> buf;
+    const size_t chunk = 1 << 20;
+    for (size_t b = 0; ok && b < pts.size(); b += chunk) {
+        const size_t e = std::min(pts.size(), b + chunk);
+        buf.resize((e - b) * 3);
+        for (size_t i = b; i < e; ++i) {
+            buf[(i - b) * 3] = std::get<0>(pts[i]);
+            buf[(i - b) * 3 + 1] = std::get<1>(pts[i]);
+            buf[(i - b) * 3 + 2] = std::get<2>(pts[i]);
+        }
+        ok = std::fwrite(buf.data(), sizeof(double), buf.size(), f) == buf.size();
+    }
+    return std::fclose(f) == 0 && ok;
+}
+
+std::vector<std::tuple<double, double, double>> pointsFromBinFile(const char *fname, int *dim)
+{
+    std::vector<std::tuple<double, double, double>> pts;
+    FILE *f = std::fopen(fname, "rb");
+    if (!f) return pts;
+    BinHeader h;
+    if (std::fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kBinMagic, 8) != 0 || h.version != 1 ||
+        (h.dim != 2 && h.dim != 3)) {
+        std::fclose(f);
+        return pts;
+    }
+    // the count is checked against the file size before anything is allocated
+    std::fseek(f, 0, SEEK_END);
+    const long long bytes = std::ftell(f);
+    if (bytes < 0 || (unsigned long long)(bytes - (long long)sizeof(h)) != h.n * 24ull) {
+        std::fclose(f);
+        return pts;
+    }
+    std::fseek(f, (long)sizeof(h), SEEK_SET);
+    pts.reserve((size_t)h.n);
+    std::vector<double> buf;
+    const size_t chunk = 1 << 20;
+    for (size_t b = 0; b < (size_t)h.n; b += chunk) {
+        const size_t e = std::min((size_t)h.n, b + chunk);
+        buf.resize((e - b) * 3);
+        if (std::fread(buf.data(), sizeof(double), buf.size(), f) != buf.size()) {
+            pts.clear();
+            break;
+        }
+        for (size_t i = 0; i < e - b; ++i) pts.emplace_back(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]);
+    }
+    std::fclose(f);
+    if (dim) *dim = (int)h.dim;
+    return pts;
 }

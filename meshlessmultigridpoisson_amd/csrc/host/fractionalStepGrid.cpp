@@ -91,6 +91,24 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 {
     const int n = laplaceMatSize_;
     ensure_knn();
+    {
+        // batched on the device when it pays (Grid::batched_stencils): kNN on the host threads, the dense
+        // solves on the MI355X; `which` maps to the operator ids 1 (d/dx), 2 (d/dy), 0 (Laplacian)
+        vector<char> isb((size_t)n);
+        for (int i = 0; i < n; ++i) isb[(size_t)i] = bcFlags_[(size_t)i] != 0;
+        vector<int> nbr;
+        vector<double> w;
+        const int ss = stencilSizeFor(properties_.polyDeg, dim_);
+        if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, {which == 0 ? 1 : (which == 1 ? 2 : 0)}, nbr, w)) {
+            vector<Triplet> trip;
+            trip.reserve((size_t)n * (size_t)ss);
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < ss; ++j) trip.emplace_back(i, nbr[(size_t)i * ss + j], w[(size_t)i * ss + j]);
+            SparseRowMajor *m = new SparseRowMajor(n, n, true);
+            m->setFromTriplets(trip.begin(), trip.end());
+            return m;
+        }
+    }
     std::vector<std::vector<double>> W((size_t)n);
     std::vector<vector<int>> NB((size_t)n);
     std::atomic<int> next{0};

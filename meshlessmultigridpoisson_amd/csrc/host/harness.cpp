@@ -539,6 +539,16 @@ void mmgh_bound_pts_conn(const char *fname, const int *bcflags, int n, int *conn
 }
 void mmgh_write_vector_txt(const double *v, int n, const char *fname) { writeVectorToTxt(std::vector<double>(v, v + n), fname); }
 int mmgh_order_from_txt(const char *fname, int nv) { return (int)orderFromTxt(fname, nv).size(); }
+// binary cloud container: returns the point count (0: missing / foreign / truncated file); *dim out
+long long mmgh_points_from_bin(const char *fname, double *xyz, long long cap, int *dim)
+{
+    int d = 0;
+    auto pts = pointsFromBinFile(fname, &d);
+    for (size_t i = 0; i < pts.size() && (long long)i < cap; ++i) { xyz[3 * i] = std::get<0>(pts[i]); xyz[3 * i + 1] = std::get<1>(pts[i]); xyz[3 * i + 2] = std::get<2>(pts[i]); }
+    if (dim) *dim = d;
+    return (long long)pts.size();
+}
+int mmgh_write_bin(const char *fname, const double *xyz, int n, int dim) { return writePointsToBinFile(fname, to_points(xyz, n), dim) ? 0 : 1; }
 int mmgh_write_msh(const char *fname, const double *xyz, int n) { return writePointsToMshFile(fname, to_points(xyz, n)) ? 0 : 1; }
 // k nearest neighbours of point `pid` with the reference's exclusion rule
 // "device_setup": -1 automatic, 0 host threads, 1 batched on the MI355X (Grid::device_setup_ of grids created afterwards)

@@ -94,6 +94,34 @@ def test_device_rbf_weights_all_operators(host):
             assert np.abs(w[o, k] - ref).max() <= 1e-6 * np.abs(ref).max(), (which, i)
 
 
+def test_device_setup_fracstep_operators_match_host_setup(host):
+    """FractionalStepGrid::build_derivX/derivY/uvLaplace (fractionalStepGrid.cpp:60-100) through the device
+    batch: same sparsity, weights to 1e-6 of the row's largest entry, and one fractional step
+    (predictor, PPE source, corrector) gives the same fields."""
+    pts = host.square_cloud(28, seed=5)
+    grids = []
+    for mode in (0, 1):
+        host.set_option("device_setup", mode)
+        grids.append(host.FracStepGrid.create(pts, polydeg=3, ordering=host.ORDER_MC, tile_points=128))
+    host.set_option("device_setup", -1)
+    gh, gd = grids
+    for which in (0, 1, 2):
+        rph, colh, valh = gh.op(which)
+        rpd, cold, vald = gd.op(which)
+        assert np.array_equal(rph, rpd) and np.array_equal(colh, cold)
+        rowmax = np.maximum.reduceat(np.abs(valh), rph[:-1])
+        assert (np.abs(vald - valh) / np.repeat(rowmax, np.diff(rph))).max() <= 1e-6, which
+    for g in (gh, gd):
+        g.prescribe_soln()
+        g.set_uv_bound()
+        g.calc_hat()
+        g.set_ppe_source()
+    for which in (2, 3):          # u_hat, v_hat
+        a, b = gh.vec(which), gd.vec(which)
+        assert np.abs(a - b).max() <= 1e-7 * max(np.abs(a).max(), 1.0)
+    assert np.abs(gh.source() - gd.source()).max() <= 1e-6 * np.abs(gh.source()).max()
+
+
 def test_device_setup_multigrid_converges_like_host_setup(host):
     """Interpolation matrices + level operators from the device batch: the V-cycle history follows the
     host-setup hierarchy (same algorithm, operators equal to ~1e-7) and reaches the manufactured solution."""

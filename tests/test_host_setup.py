@@ -184,3 +184,39 @@ def test_fracstep_operators_match_numpy_oracle_and_kovasznay(host):
     dx = sp.csr_matrix((g.op(0)[2], g.op(0)[1], g.op(0)[0]), shape=(len(u), len(u)))
     exact = -lam * np.exp(lam * xyz[:, 0]) * np.cos(2 * np.pi * xyz[:, 1])
     assert np.abs(dx @ u - exact)[flags == 0].mean() < 5e-2
+
+
+def test_binary_cloud_container_round_trip(tmp_path):
+    """binary cloud format for 1e7+ points next to the reference's MSH / txt readers.
+    Bitwise round trip, equal to what the MSH reader returns for the same cloud, loud on bad input."""
+    from meshlessmultigridpoisson_amd import _host as host
+    pts = host.box_cloud(9, 3, seed=3)
+    f = str(tmp_path / "cloud.mmgc")
+    host.write_cloud_bin(f, pts, 3)
+    assert os.path.getsize(f) == 24 + 24 * len(pts)
+    back, dim = host.read_cloud_bin(f)
+    assert dim == 3 and np.array_equal(back, pts)
+    # the same cloud through the reference's text format: %.17g text -> identical doubles
+    msh = str(tmp_path / "cloud.msh").encode()
+    assert host.lib().mmgh_write_msh(msh, pts.ctypes.data_as(_dp), len(pts)) == 0
+    txt = np.zeros_like(pts)
+    assert host.lib().mmgh_points_from_msh(msh, txt.ctypes.data_as(_dp), len(pts), 0) == len(pts)
+    assert np.array_equal(txt, back)
+    # truncated, foreign and missing files are refused
+    raw = open(f, "rb").read()
+    open(f, "wb").write(raw[:-8])
+    with pytest.raises(host.HostError):
+        host.read_cloud_bin(f)
+    open(f, "wb").write(b"NOTCLOUD" + raw[8:])
+    with pytest.raises(host.HostError):
+        host.read_cloud_bin(f)
+    with pytest.raises(host.HostError):
+        host.read_cloud_bin(str(tmp_path / "missing.mmgc"))
+    # a 2-D cloud through a Grid: same operator as from the in-memory points
+    p2 = host.square_cloud(17, seed=2)
+    host.write_cloud_bin(f, p2, 2)
+    q2, d2 = host.read_cloud_bin(f)
+    assert d2 == 2
+    ga = host.Grid.create_square(p2, 3, ordering=host.ORDER_NONE)
+    gb = host.Grid.create_square(q2, 3, ordering=host.ORDER_NONE)
+    assert all(np.array_equal(a, b) for a, b in zip(ga.csr(), gb.csr()))
