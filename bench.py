@@ -95,6 +95,11 @@ def cpu_baseline(grid, stencil, budget_s):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE JSON line.  RCCL prints a version banner on stdout when a communicator is
+    # created (torch's and the library's own): everything but the final line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,6 +212,21 @@ def main():
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # residual SpMV on the same level (Grid::residual, grid.cpp:147-151, + the two L1 norms of
+    # Multigrid::residual): r = b - A x over the same packed stream, HIP events on the library's stream
+    res_ms = float(np.median(lv.time_residual(7)[1:]))
+    if dist is not None:
+        import torch
+        t = torch.tensor([res_ms], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res_ms = float(t.item())
+    b_res = 12 * stencil + 24
+    spmv = {"what": "residual r = b - A x with Dirichlet mask and L1 norms (Grid::residual / Multigrid::residual)",
+            "value": total_points / (res_ms * 1e-3) / 1e6, "unit": "Mrows/s", "ms": res_ms,
+            "algorithmic_bytes_per_row": b_res,
+            "achieved": interior * b_res / (res_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit_bw": "GB/s",
+            "frac": interior * b_res / (res_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
     # HBM bytes per launch from the PMC counters of the committed profile of this same workload
     # (profiles/collect.sh: rocprofv3 --pmc passes cannot run inside the timed process)
     traffic, traffic_src = None, None
@@ -259,11 +279,15 @@ def main():
                 "algorithmic_bytes_per_row": b_sor(stencil),
             },
         }
+        out["spmv"] = spmv
         if verify is not None:
             out["config"]["persistent_vs_phase_launches"] = verify
         if not a.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(grid, stencil, a.cpu_seconds)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dd:
         _capi.comm_finalize()
     if dist is not None:
