@@ -200,7 +200,7 @@ hipError_t run_tiles(const PlanGpu &pl, TileMode mode, const TileArgs &a, hipStr
     return pl.exact ? launch_tile_kernel_exact(mode, a, s) : launch_tile_kernel(mode, a, s);
 }
 
-// One phase of a relaxation sweep.  Phases of at most a few tiles per CU (the coarse levels of a
+// One phase of a relaxation sweep.  Phases of at most one tile per CU (the coarse levels of a
 // V-cycle) are latency-bound -- one tile's dependency chain, ~28 groups x one global-load latency --
 // and run with the tile's whole packed stream resident in LDS instead (kernels.hip: tile_kernel_lds).
 hipError_t run_sor_phase(const PlanGpu &pl, const TileArgs &a, hipStream_t s)
@@ -215,7 +215,7 @@ hipError_t run_sor_phase(const PlanGpu &pl, const TileArgs &a, hipStream_t s)
         } else cus = -1;
     }
     const bool small = g_lds_resident && !pl.exact && cus > 0 && (pl.dev.L == 2 || pl.dev.L == 4) &&
-                       pl.dev.lds_bytes_resident <= (unsigned)lds_cu && a.n_list <= (g_lds_resident > 1 ? g_lds_resident : 2) * cus;
+                       pl.dev.lds_bytes_resident <= (unsigned)lds_cu && a.n_list <= (g_lds_resident > 1 ? g_lds_resident : 1) * cus;  // one workgroup per CU: a second round would cost what it saves
     if (small) return launch_tile_kernel_lds(a, s);
     return run_tiles(pl, MODE_SOR, a, s);
 }
@@ -336,6 +336,27 @@ bool use_single_launch(const mmg_level *lv)
     return true;
 }
 
+// Tiny level: every tile resident at once (at most one per CU, stream + inputs within the CU's LDS).
+// Then all phases -- and fused sweeps -- run as ONE launch with the streams kept in LDS (kernels.hip:
+// sweep_resident_kernel) instead of phases x sweeps launches of ~20 us each.
+bool use_resident_sweep(const mmg_level *lv)
+{
+    static int cus = 0, lds_cu = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
+            cus = p.multiProcessorCount;
+            lds_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+        } else cus = -1;
+    }
+    if (g_persistent_sweep != 1) return false;  // 0: strictly one launch per phase; 2, 4: the ticket kernel is forced
+    if (g_lds_resident == 0 || g_lds_resident == 3 || cus <= 0 || lv->A.exact || lv->A.n_phases() <= 1) return false;  // 3: per-phase LDS kernel only (A/B)
+    if (lv->distributed && lv->exchange_per_phase) return false;
+    if (!(lv->A.dev.L == 2 || lv->A.dev.L == 4) || !lv->sync_words.p) return false;
+    return lv->A.n_tiles <= cus && lv->A.dev.lds_bytes_resident <= (unsigned)lds_cu;
+}
+
 int allreduce_sum(double *p, int count)
 {
     if (g_rccl.comm && g_rccl.nranks > 1) NCCLC(g_rccl.AllReduce(p, p, (size_t)count, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
@@ -366,7 +387,22 @@ int sweep_some(mmg_level *lv, int k, int *done)
     a.lambda = lv->neumann ? lv->x.p + lv->n : nullptr;
     a.flags8 = lv->flags8.p;
     a.partial = lv->neumann ? lv->partX.p : nullptr;
-    if (use_single_launch(lv)) {
+    if (use_resident_sweep(lv)) {
+        a.tile_list = lv->A.dev.phase_tiles;
+        a.n_list = lv->A.n_tiles;
+        a.ticket = lv->sync_words.p;
+        a.error = lv->sync_words.p + 1;
+        a.done = lv->sync_words.p + 2;
+        const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
+        const int ns = fusable ? std::min(k, 16) : 1;
+        a.epoch = lv->epoch + 1;
+        a.n_sweeps = ns;
+        lv->epoch += (unsigned)ns;
+        if ((erc = mark_event())) return erc;
+        HIPC(launch_sweep_resident(a, g_stream));
+        if ((erc = mark_event())) return erc;
+        *done = ns;
+    } else if (use_single_launch(lv)) {
         // one launch: tiles in phase order, started by their dependencies (kernels.hip)
         a.tile_list = lv->A.dev.phase_tiles;
         a.n_list = lv->A.n_tiles;

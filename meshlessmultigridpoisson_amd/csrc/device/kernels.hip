@@ -155,7 +155,8 @@ __device__ __forceinline__ void st_x(double *p, double v)
 // One wavefront per tile.  LDS: xs[n_slots] (inputs) | bs[n_own] (rhs of the own
 // range, SOR/RESID) | gh[n_groups] (group heads).
 template <int L, int MODE, int MAXP, bool SC1, int BITS, bool LDSS = false>
-__device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, unsigned char *smem, const double lam)
+__device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, unsigned char *smem, const double lam,
+                                             const bool load_stream = true)
 {
     double *xs = reinterpret_cast<double *>(smem);
     const int lane = threadIdx.x;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     // 1-KiB chunk is in flight at once instead of 8 loads per lane), default cache policy (a small
     // level's matrix stays in L2/MALL from sweep to sweep); the groups then run at LDS latency.
     const size_t lds_stream_off = ((size_t)(n_slots + (kUsesB ? n_own : 0)) * 8 + (size_t)n_groups * 4 + 15) & ~(size_t)15;
-    if constexpr (LDSS) {
+    if constexpr (LDSS) if (load_stream) {  // sweep_resident_kernel keeps the copy across sweeps
         const unsigned char *src = a.p.stream + td.stream_off;
         const uint32_t n16 = td.stream_len >> 4;  // 16-byte units; the last chunk may be partial
         for (uint32_t c = 0; c * 64 < n16; ++c) {
@@ -396,6 +397,52 @@ __global__ __launch_bounds__(64) void tile_kernel_lds(TileArgs a)
     double lam = 0.0;
     if (a.lambda) lam = *a.lambda;
     process_tile<L, MODE_SOR, MAXP, false, BITS, true>(a, tile, smem, lam);
+}
+
+// Whole sweeps of a TINY level (every tile resident at once: at most one tile per CU) in ONE launch:
+// workgroup b owns tile b for all phases and all fused sweeps, pulls its packed stream into LDS once
+// and keeps it there; per sweep it only waits for its coupled tiles (the flags of the dependency-driven
+// sweep below), re-stages x and walks its groups at LDS latency.  Replaces phases x sweeps launches of
+// ~20 us each on the coarsest V-cycle levels.  Progress needs all workgroups co-resident (grid <= CUs,
+// checked by the launcher); waits are bounded and report through the error word, never hang.
+template <int L, int MAXP, int BITS>
+__global__ __launch_bounds__(64) void sweep_resident_kernel(TileArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_list) return;
+    const int tile = a.tile_list[blockIdx.x];
+    double lam = 0.0;
+    if (a.lambda) lam = *a.lambda;
+    const int d0 = a.p.dep_ptr[tile], d1 = a.p.dep_ptr[tile + 1];
+    const int l0 = a.p.later_ptr[tile], l1e = a.p.later_ptr[tile + 1];
+    for (int sw = 0; sw < a.n_sweeps; ++sw) {
+        const unsigned want_now = a.epoch + (unsigned)sw;       // earlier coupled tiles: this sweep done
+        const unsigned want_prev = a.epoch + (unsigned)sw - 1;  // later coupled tiles: previous sweep done
+        const int l1 = sw > 0 ? l1e : l0;
+        const int n_wait = (d1 - d0) + (l1 - l0);
+        for (int base = 0; base < n_wait; base += 64) {
+            const int k = base + lane;
+            const bool mine = k < n_wait;
+            const bool early = k < (d1 - d0);
+            const int dep = !mine ? tile : (early ? a.p.dep_idx[d0 + k] : a.p.later_idx[l0 + (k - (d1 - d0))]);
+            const unsigned need = early ? want_now : want_prev;
+            const unsigned *flag = a.done + dep;
+            bool ok = !mine;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (!ok) ok = (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!__all(ok) && lane == 0) atomicOr(a.error, 1u);
+        }
+        // x goes through agent-scope (sc1) accesses as in sweep_persistent_kernel; the matrix stream is
+        // read-only and lands in LDS once (sw == 0)
+        process_tile<L, MODE_SOR, MAXP, true, BITS, true>(a, tile, smem, lam, sw == 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+    }
 }
 
 // Dependency-driven sweep: ONE launch per sweep.  Resident wavefronts draw tiles from a
@@ -919,6 +966,40 @@ hipError_t launch_tile_kernel_lds(const TileArgs &a, hipStream_t s)
     const bool b12 = a.p.slot_bits == 12;
     if (a.p.L == 2) return b12 ? launch_lds_LB<2, 12>(a, s) : launch_lds_LB<2, 16>(a, s);
     if (a.p.L == 4) return b12 ? launch_lds_LB<4, 12>(a, s) : launch_lds_LB<4, 16>(a, s);
+    return hipErrorInvalidValue;
+}
+
+template <int L, int MAXP, int BITS>
+hipError_t launch_res_LPB(const TileArgs &a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_resident_kernel<L, MAXP, BITS>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((sweep_resident_kernel<L, MAXP, BITS>), dim3((unsigned)a.n_list), dim3(64), a.p.lds_bytes_resident, s, a);
+    return hipGetLastError();
+}
+template <int L, int BITS>
+hipError_t launch_res_LB(const TileArgs &a, hipStream_t s)
+{
+    const int mp = a.p.max_plen;
+    if (mp <= 8) return launch_res_LPB<L, 8, BITS>(a, s);
+    if (mp <= 16) return launch_res_LPB<L, 16, BITS>(a, s);
+    if (mp <= 28) return launch_res_LPB<L, 28, BITS>(a, s);
+    if (mp <= 64) return launch_res_LPB<L, 64, BITS>(a, s);
+    return hipErrorInvalidValue;
+}
+// all phases (and a.n_sweeps fused sweeps) of a level whose tiles are all resident at once;
+// the caller guarantees a.n_list <= compute units and lds_bytes_resident <= LDS per CU
+hipError_t launch_sweep_resident(const TileArgs &a, hipStream_t s)
+{
+    if (a.n_list <= 0) return hipSuccess;
+    const bool b12 = a.p.slot_bits == 12;
+    if (a.p.L == 2) return b12 ? launch_res_LB<2, 12>(a, s) : launch_res_LB<2, 16>(a, s);
+    if (a.p.L == 4) return b12 ? launch_res_LB<4, 12>(a, s) : launch_res_LB<4, 16>(a, s);
     return hipErrorInvalidValue;
 }
 

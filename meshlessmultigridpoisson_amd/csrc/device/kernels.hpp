@@ -57,6 +57,10 @@ hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
 // SOR phase with the tile's packed stream resident in LDS: one workgroup per tile, for phases of at
 // most a few tiles per CU (latency-bound small levels).  L = 2 / 4 plans with lds_bytes_resident <= LDS per CU.
 hipError_t launch_tile_kernel_lds(const TileArgs &a, hipStream_t s);
+// Tiny levels (n_list = ALL tiles of the level <= compute units): every phase and a.n_sweeps fused sweeps in one
+// launch, each workgroup keeping its tile's stream in LDS throughout; ticket/done/epoch/error as for
+// launch_sweep_persistent (no ticket needed: workgroup b owns tile tile_list[b]).
+hipError_t launch_sweep_resident(const TileArgs &a, hipStream_t s);
 // exact-arithmetic variant (plans built with exact = true, L = 1): every row is accumulated by
 // one lane in the reference's stored order with separately rounded multiply and add
 hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_t s);

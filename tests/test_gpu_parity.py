@@ -392,6 +392,41 @@ def test_lds_resident_phase_kernel_and_12bit_slots_change_no_bit(name, tile, L):
         assert np.array_equal(xs[key], xs["plain"]), key
 
 
+@pytest.mark.parametrize("name", ["dirichlet_3level", "neumann_3level", "dirichlet_2level_inhomog"])
+def test_resident_whole_sweep_kernel_matches_oracle_and_phase_launches(name):
+    """Tiny levels (all tiles resident at once) run ALL phases and fused sweeps in one launch with the tile
+    streams kept in LDS (sweep_resident_kernel; default for such levels).  Iterates: bitwise those of the
+    per-phase launches, oracle to 1e-12; the V-cycle history (which now runs through this kernel on every
+    level of the fixtures) to 1e-10."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    for lvl in range(case["nlevels"]):
+        la = H.level_arrays(case, lvl)
+        o = H.oracle_level(la)
+        o.boundary_op(0)
+        xs = {}
+        try:
+            for key, pers in (("phase", 0), ("resident", 1)):
+                _capi.set_option("persistent_sweep", pers)
+                d = H.device_level(la, tile_size=48, lanes_per_row=4)
+                d.boundary_op(0)
+                d.sweeps(7)                    # Dirichlet levels: one launch carrying 7 sweeps
+                xs[key] = d.get_x()
+        finally:
+            _capi.set_option("persistent_sweep", 1)
+        o.sor_sweeps(7)
+        assert H.rel_err(xs["resident"], o.x) < 1e-12, lvl
+        assert np.array_equal(xs["resident"], xs["phase"]), lvl
+    om = H.oracle_multigrid(case)
+    dh = H.device_hierarchy(case)
+    for k in range(8):
+        ro, rd = om.vcycle(), dh.vcycle()
+        if ro < 0:
+            continue
+        assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
+
+
 def test_lds_resident_phase_kernel_3d_k50():
     """The same on the 3-D K = 50 stencils of the coarse V-cycle levels (135 KB of stream per 256-point tile,
     more than 64 KiB of dynamic LDS per workgroup), including the single-launch sweep with 12-bit slots."""
