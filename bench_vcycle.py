@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--cycles", type=int, default=20)
     ap.add_argument("--polydeg", type=int, default=4)
     ap.add_argument("--persistent", type=int, default=1)
+    ap.add_argument("--omega", type=float, default=1.4, help="SOR factor (reference default 1.4, testing_functions.cpp)")
+    ap.add_argument("--iters", type=int, default=5, help="sweeps per smoothing call (reference default 5)")
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
     ap.add_argument("--oracle-cycles", type=int, default=0, help="also run this many cycles on the CPU oracle")
     a = ap.parse_args()
@@ -36,13 +38,14 @@ def main():
     else:
         clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
     polys = [3] * (a.levels - 1) + [a.polydeg]
-    mg = _host.Multigrid(clouds, polys, dim=a.dim, neumann=False, ordering=_host.ORDER_MC, tile_points=0)
+    mg = _host.Multigrid(clouds, polys, dim=a.dim, neumann=False, ordering=_host.ORDER_MC, tile_points=0,
+                         omega=a.omega, iters=a.iters)
     t_setup = time.perf_counter() - t0
     res, ms = mg.vcycles(3)  # warm-up, creates the device hierarchy
     t0 = time.perf_counter()
     res, ms = mg.vcycles(a.cycles)
     wall = time.perf_counter() - t0
-    out = {"workload": f"{a.dim}-D {sides[-1]}^{a.dim} = {sides[-1] ** a.dim} points, {a.levels} levels {sides}, polyDeg {polys}",
+    out = {"workload": f"{a.dim}-D {sides[-1]}^{a.dim} = {sides[-1] ** a.dim} points, {a.levels} levels {sides}, polyDeg {polys}, omega {a.omega}, iters {a.iters}",
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
            "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
            "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
