@@ -60,6 +60,7 @@ def parse():
                          "lists) even with one rank -- rehearsal of the N>1 path on a 1-GPU box")
     ap.add_argument("--slot-bits", type=int, default=16, choices=(12, 16),
                     help="width of the tile-local column indices in the packed matrix stream (A/B)")
+    ap.add_argument("--resid-lds", type=int, default=1, help="0: residual rows stored straight to HBM (A/B)")
     ap.add_argument("--exchange", choices=("sweep", "phase"), default="sweep",
                     help="N>1: ghost refresh once per sweep (block-hybrid Gauss-Seidel, default) or before every phase "
                          "(exact: the sequential reference sweep on the global system)")
@@ -115,6 +116,7 @@ def main():
     _capi.check(_capi.lib().mmg_set_device(local_rank))
     _capi.set_option("persistent_sweep", a.persistent)
     _capi.set_option("slot_bits", a.slot_bits)
+    _capi.set_option("resid_lds", a.resid_lds)
 
     # ---- setup (untimed): cloud -> ordering -> operator -> packed device layout ----
     t_setup = time.perf_counter()

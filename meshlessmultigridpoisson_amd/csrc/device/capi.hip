@@ -32,6 +32,7 @@ bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created a
 // pairs (1125/1071/1075 vs 1086/1024/1016 us per sweep at 1e7 points): the sweep is not purely byte-bound,
 // the straddling decode costs more than the bytes save.  Kept as an option, default 16.
 int g_slot_bits = 16;
+int g_resid_lds = 1;  // mmg_set_option("resid_lds", 0 | 1): residual rows leave a tile through LDS, coalesced
 int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident tile streams for the phases of small levels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
 thread_local hipStream_t g_stream = nullptr;
@@ -521,6 +522,7 @@ int residual_dev(mmg_level *lv, bool norms)
     a.flags8 = lv->flags8.p;
     a.partial = lv->partA.p;
     a.partial2 = lv->neumann ? lv->partX.p : nullptr;
+    a.resid_lds = (g_resid_lds && !lv->A.exact) ? 1 : 0;
     HIPC(run_tiles(lv->A, MODE_RESID, a, g_stream));
     if (!lv->B.empty()) {
         TileArgs c{};
@@ -721,6 +723,7 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "exact_arithmetic") == 0) { g_exact = value != 0; return MMG_OK; }
     if (std::strcmp(name, "slot_bits") == 0) { g_slot_bits = value == 12 ? 12 : 16; return MMG_OK; }
     if (std::strcmp(name, "lds_resident") == 0) { g_lds_resident = value; return MMG_OK; }
+    if (std::strcmp(name, "resid_lds") == 0) { g_resid_lds = value != 0; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -289,7 +289,10 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
                 const double bi = (m.self < n_own) ? bs[m.self] : a.b[m.gid];
                 double rr = bi - (acc + r.d * xs[m.self]);
                 if (m.flags & 1) rr -= lam;
-                a.out[m.gid] = rr;
+                // level plans: the row's rhs slot is dead now, r goes there and leaves the tile in one
+                // coalesced pass (scattered 8-byte stores otherwise)
+                if (a.resid_lds && m.self < n_own) bs[m.self] = rr;
+                else a.out[m.gid] = rr;
                 local += fabs(rr);
             } else if (MODE == MODE_SET) {
                 a.out[m.gid] = acc;
@@ -354,6 +357,10 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         }
     }
     if (MODE == MODE_RESID) {
+        // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
+        // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan (residual_dev)
+        if (a.resid_lds)
+            for (uint32_t i = lane; i < n_own; i += 64) a.out[td.row0 + i] = bs[i];
         if (a.partial) {
             local = wave_sum(local);
             if (lane == 0) a.partial[tile] = local;

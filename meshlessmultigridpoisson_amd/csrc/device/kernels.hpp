@@ -51,6 +51,7 @@ struct TileArgs {
     int n_sweeps;              // sweeps fused into this launch (tickets run over n_sweeps * n_list)
     unsigned *error;           // set when a dependency wait times out
     int fence;                 // 1: add agent-scope acquire/release fences around every tile
+    int resid_lds;             // RESID over a level plan: keep r in LDS, write the own range back coalesced
 };
 
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);

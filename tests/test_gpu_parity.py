@@ -427,6 +427,31 @@ def test_resident_whole_sweep_kernel_matches_oracle_and_phase_launches(name):
         assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
 
 
+@pytest.mark.parametrize("name", ["dirichlet_3level", "neumann_3level", "dirichlet_2level_inhomog"])
+def test_residual_rows_through_lds_change_no_bit(name):
+    """Grid::residual (grid.cpp:147-151): by default the rows of a tile are collected in LDS and leave it in one
+    coalesced pass; mmg_set_option("resid_lds", 0) stores them one by one.  Same r (bitwise, every entry incl.
+    masked Dirichlet rows, Neumann rows and the multiplier row), same norms, and the oracle's r."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    for lvl in range(case["nlevels"]):
+        la = H.level_arrays(case, lvl)
+        la["x0"] = np.random.default_rng(lvl).standard_normal(la["a_size"])
+        o = H.oracle_level(la)
+        ro = o.residual()
+        out = {}
+        try:
+            for opt in (0, 1):
+                _capi.set_option("resid_lds", opt)
+                d = H.device_level(la, tile_size=40, lanes_per_row=4)
+                out[opt] = (d.residual(), d.residual_ratio())
+        finally:
+            _capi.set_option("resid_lds", 1)
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1], lvl
+        assert H.rel_err(out[1][0], ro) < 1e-12, lvl
+
+
 def test_lds_resident_phase_kernel_3d_k50():
     """The same on the 3-D K = 50 stencils of the coarse V-cycle levels (135 KB of stream per 256-point tile,
     more than 64 KiB of dynamic LDS per workgroup), including the single-launch sweep with 12-bit slots."""

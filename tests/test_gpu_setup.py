@@ -42,7 +42,7 @@ def _csr_rows(g):
     return rp, col, val
 
 
-@pytest.mark.parametrize("dim,nside,deg", [(2, 40, 3), (2, 40, 4), (2, 30, 5), (3, 12, 3)])
+@pytest.mark.parametrize("dim,nside,deg", [(2, 40, 3), (2, 40, 4), (2, 30, 5), (2, 26, 6), (3, 12, 3)])  # deg 6: 98 x 98 system, 77 KB of LDS per workgroup
 def test_device_laplacian_matches_host_setup(host, dim, nside, deg):
     pts = host.box_cloud(nside, dim, seed=12345) if dim == 3 else host.square_cloud(nside, seed=12345)
     host.set_option("device_setup", 0)
