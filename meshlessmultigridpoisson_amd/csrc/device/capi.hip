@@ -794,7 +794,15 @@ int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per
             if (lds * 6 > 0.97 * lds_bytes_per_cu) break;
             big = t;
         }
-        if (big > best && (double)n_points / big >= 2.0 * 6 * compute_units) best = big;
+        // Mid-size levels are bound by the critical path of a sweep -- 8 phases x one tile's duration (~54 us
+        // at best) -- not by bandwidth, and small tiles keep that duration short: at 160^3 = 4.1e6 points
+        // T 256 -> 51.9 %, 384 -> 50.5 %, 640 -> 43.5 %, 896 -> 42.4 %; at 128^3 256 is best as well, at 100^3
+        // the sweep takes 0.43 ms whatever the tile.  The large tile pays once a sweep is 6+ residency rounds.
+        // 171^3 = 5.0e6: T 256 / 384 / 896 -> 52.4 / 55.2 / 49.4 %; 190^3 = 6.9e6: 51.9 / 61.9 / 56.9 %.
+        const double rounds_big = big > 0 ? (double)n_points / big / (6.0 * compute_units) : 0.0;
+        if (big > best && rounds_big >= 6.0) best = big;
+        else if (rounds_big >= 2.0) best = 384;
+        else if (best > 256) best = 256;
     }
     return best;
 }
