@@ -60,6 +60,8 @@ def parse():
                          "lists) even with one rank -- rehearsal of the N>1 path on a 1-GPU box")
     ap.add_argument("--slot-bits", type=int, default=16, choices=(12, 16),
                     help="width of the tile-local column indices in the packed matrix stream (A/B)")
+    ap.add_argument("--lds-resident", type=int, default=1,
+                    help="0: off; 1: LDS-resident tile streams for phases of <= 1 tile per CU; k > 1: up to k tiles per CU (A/B)")
     ap.add_argument("--resid-lds", type=int, default=1, help="0: residual rows stored straight to HBM (A/B)")
     ap.add_argument("--exchange", choices=("sweep", "phase"), default="sweep",
                     help="N>1: ghost refresh once per sweep (block-hybrid Gauss-Seidel, default) or before every phase "
@@ -117,6 +119,7 @@ def main():
     _capi.set_option("persistent_sweep", a.persistent)
     _capi.set_option("slot_bits", a.slot_bits)
     _capi.set_option("resid_lds", a.resid_lds)
+    _capi.set_option("lds_resident", a.lds_resident)
 
     # ---- setup (untimed): cloud -> ordering -> operator -> packed device layout ----
     t_setup = time.perf_counter()
