@@ -37,6 +37,9 @@ int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident 
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
+// Error word of the dependency-driven kernels (a bounded wait ran out): one word in pinned, device-mapped
+// host memory, so every call that synchronises anyway can look at it for free.
+unsigned *g_err_host = nullptr, *g_err_dev = nullptr;
 
 int fail(int code, const std::string &msg)
 {
@@ -59,6 +62,11 @@ int ensure_device()
     if (!g_stream) {
         HIPC(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         g_own_stream = true;
+    }
+    if (!g_err_host) {
+        HIPC(hipHostMalloc(reinterpret_cast<void **>(&g_err_host), sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
+        *g_err_host = 0u;
+        HIPC(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_err_dev), g_err_host, 0));
     }
     return MMG_OK;
 }
@@ -392,7 +400,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.tile_list = lv->A.dev.phase_tiles;
         a.n_list = lv->A.n_tiles;
         a.ticket = lv->sync_words.p;
-        a.error = lv->sync_words.p + 1;
+        a.error = g_err_dev;
         a.done = lv->sync_words.p + 2;
         const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
         const int ns = fusable ? std::min(k, 16) : 1;
@@ -408,7 +416,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.tile_list = lv->A.dev.phase_tiles;
         a.n_list = lv->A.n_tiles;
         a.ticket = lv->sync_words.p;
-        a.error = lv->sync_words.p + 1;
+        a.error = g_err_dev;
         a.done = lv->sync_words.p + 2;
         // several sweeps per launch when nothing sits between them (no multiplier row, no Neumann
         // boundary solve, no ghost exchange): the queue simply runs over sweeps x tiles
@@ -459,14 +467,21 @@ int sweep_some(mmg_level *lv, int k, int *done)
     return MMG_OK;
 }
 
+// call after the stream has been synchronised
+int sync_error_seen()
+{
+    if (g_err_host && *reinterpret_cast<volatile unsigned *>(g_err_host)) {
+        *g_err_host = 0u;
+        return fail(MMG_ERR_HIP, "dependency-driven sweep: a tile's wait for its coupled tiles timed out (results invalid)");
+    }
+    return MMG_OK;
+}
+
 int check_sync_error(mmg_level *lv)
 {
     if (!lv->sync_words.p || lv->epoch == 0) return MMG_OK;
-    unsigned e = 0;
-    HIPC(hipMemcpyAsync(&e, lv->sync_words.p + 1, sizeof(unsigned), hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
-    if (e) return fail(MMG_ERR_HIP, "persistent sweep: a tile dependency wait timed out");
-    return MMG_OK;
+    return sync_error_seen();
 }
 
 int bound_eval(mmg_level *lv)
@@ -562,7 +577,7 @@ int residual_ratio(mmg_level *lv, double *ratio)
     HIPC(hipMemcpyAsync(h, lv->scal.p, sizeof(h), hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     *ratio = h[0] / h[1];
-    return MMG_OK;
+    return sync_error_seen();  // every V-cycle passes here (residuals_.push_back): timed-out waits surface at once
 }
 
 int boundary_op(mmg_level *lv, int coarse)

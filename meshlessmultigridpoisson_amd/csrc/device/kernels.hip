@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64) void sweep_resident_kernel(TileArgs a)
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (!__all(ok) && lane == 0) atomicOr(a.error, 1u);
+            if (!__all(ok) && lane == 0) *reinterpret_cast<volatile unsigned *>(a.error) = 1u;  // pinned host word
         }
         // x goes through agent-scope (sc1) accesses as in sweep_persistent_kernel; the matrix stream is
         // read-only and lands in LDS once (sw == 0)
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
             }
-            if (!__all(ok) && lane == 0) atomicOr(a.error, 1u);  // never hang: report and go on
+            if (!__all(ok) && lane == 0) *reinterpret_cast<volatile unsigned *>(a.error) = 1u;  // pinned host word  // never hang: report and go on
         }
         // Every access to x in this kernel is an sc1 (agent-scope) load or store, the stores
         // are drained before the flag is published and the flag is polled with sc1 loads: the

@@ -49,7 +49,7 @@ struct TileArgs {
     unsigned *done;            // per tile: epoch of the last completed sweep
     unsigned epoch;            // value a tile publishes after its FIRST sweep of this launch
     int n_sweeps;              // sweeps fused into this launch (tickets run over n_sweeps * n_list)
-    unsigned *error;           // set when a dependency wait times out
+    unsigned *error;           // set (plain store of 1; pinned, device-mapped host word) when a dependency wait times out
     int fence;                 // 1: add agent-scope acquire/release fences around every tile
     int resid_lds;             // RESID over a level plan: keep r in LDS, write the own range back coalesced
 };
