@@ -308,17 +308,6 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     // compiler has to assume the current group's loads are the youngest in flight and waits
     // for everything (vmcnt(0)), serialising load latency and compute.
 #ifndef MMG_UNCOND_ISSUE  // default: prefetch only when a next group exists (A/B: +3 % at 1e7 points, -4 % on small levels)
-#ifdef MMG_TOUCH_AHEAD
-    // experiment: one dword per 128-byte line of the 8 KiB after the group being issued, default cache policy --
-    // the lines are in L2 when the real (register) loads of the next group are issued one trip later
-    const unsigned char *tile_end = a.p.stream + td.stream_off + td.stream_len;
-    unsigned tva = 0, tvb = 0, tacc = 0;
-    auto touch = [&](const unsigned char *from) -> unsigned {
-        const unsigned char *q = from + (size_t)lane * 128;
-        q = q < tile_end ? q : tile_end - 4;
-        return *reinterpret_cast<const unsigned *>(q);
-    };
-#endif
     for (uint32_t g = 0; g < n_groups; g += 2) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
         const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
@@ -326,9 +315,6 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         if (g + 1 < n_groups) {
             h1 = gh[g + 1];
             issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-#ifdef MMG_TOUCH_AHEAD
-            if (!LDSS) { tacc ^= tva; tva = touch(p1 + group_bytes_dev<BITS>(L, (int)(h1 & 0xffu), (int)(h1 >> 8))); }
-#endif
         }
         finish(ra, nr0, pl0);
         if (g + 1 >= n_groups) break;
@@ -337,15 +323,9 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         if (g + 2 < n_groups) {
             h_cur = gh[g + 2];
             issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
-#ifdef MMG_TOUCH_AHEAD
-            if (!LDSS) { tacc ^= tvb; tvb = touch(p + group_bytes_dev<BITS>(L, (int)(h_cur & 0xffu), (int)(h_cur >> 8))); }
-#endif
         }
         finish(rb, nr1, pl1);
     }
-#ifdef MMG_TOUCH_AHEAD
-    if ((tacc ^ tva ^ tvb) == 0x12345u && a.n_list < 0) xs[0] = 0.0;  // keeps the touch loads alive; never taken
-#endif
 #else
     for (uint32_t g = 0; g < n_groups; g += 2) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
