@@ -742,6 +742,15 @@ int mmg_set_option(const char *name, int value)
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
+#ifdef MMG_DEBUG_TIMING
+int mmg_debug_timing(unsigned long long *out8)
+{
+    HIPC(hipStreamSynchronize(g_stream));
+    HIPC(mmg::debug_timing_get(out8));
+    return MMG_OK;
+}
+#endif
+
 int mmg_synchronize(void)
 {
     int rc = ensure_device();

@@ -15,6 +15,13 @@
 
 namespace mmg {
 
+#ifdef MMG_DEBUG_TIMING
+// development aid (never in the shipped library): s_memrealtime stamps (100 MHz) of workgroup 0 of a
+// per-phase SOR launch: [0] entry [1] inputs staged [2] groups done [3] own range written [4] groups [5] tile
+__device__ unsigned long long g_dbg[8];
+hipError_t debug_timing_get(unsigned long long *out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg), sizeof(g_dbg)); }
+#endif
+
 namespace {
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -160,6 +167,10 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 {
     double *xs = reinterpret_cast<double *>(smem);
     const int lane = threadIdx.x;
+#ifdef MMG_DEBUG_TIMING
+    const bool dbg = MODE == MODE_SOR && !SC1 && blockIdx.x == 8;
+    if (dbg && lane == 0) g_dbg[0] = wall_clock64();
+#endif
     const TileDesc td = a.p.tiles[tile];
     const uint32_t n_own = td.n_own, n_halo = td.n_halo, n_groups = td.n_groups;
     const uint32_t n_slots = n_own + n_halo + 1;
@@ -260,6 +271,9 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     if (n_groups) issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
     __syncthreads();
 
+#ifdef MMG_DEBUG_TIMING
+    if (dbg && lane == 0) { g_dbg[1] = wall_clock64(); g_dbg[4] = n_groups; g_dbg[5] = (unsigned long long)tile; }
+#endif
     const int sub = lane & (L - 1);
     double local = 0.0;  // RESID: sum |r|
 
@@ -302,29 +316,37 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         }
     };
 
-    // Two groups per trip so the register sets alternate without copies.  The next group's
-    // loads are issued UNCONDITIONALLY (past the end the last group is simply re-read): a
-    // conditional issue would create a control-flow join in front of finish() at which the
-    // compiler has to assume the current group's loads are the youngest in flight and waits
-    // for everything (vmcnt(0)), serialising load latency and compute.
-#ifndef MMG_UNCOND_ISSUE  // default: prefetch only when a next group exists (A/B: +3 % at 1e7 points, -4 % on small levels)
-    for (uint32_t g = 0; g < n_groups; g += 2) {
+    // Two groups per trip so the register sets alternate without copies.
+#ifndef MMG_UNCOND_ISSUE
+    // Steady state: while two more groups exist both issues are unconditional, so no control-flow join sits
+    // between an issue and the finish() of the group before it -- the compiler's s_waitcnt then counts
+    // exactly (vmcnt = the loads of the group just issued) and the loads of group g+1 really fly while
+    // group g is reduced.  With `if (g + 1 < n_groups) issue(...)` inside the loop the merged wait state
+    // was vmcnt(3): every finish() waited for the prefetch it had just issued (ISA, round 1g; in-kernel
+    // stamps: 1.9 us per group on a latency-bound level, 1.3 us even with the stream in LDS).
+    uint32_t g = 0;
+    while (g + 2 < n_groups) {
         const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
         const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
-        uint32_t h1 = 0;
-        if (g + 1 < n_groups) {
-            h1 = gh[g + 1];
-            issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-        }
+        const uint32_t h1 = gh[g + 1];
+        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
         finish(ra, nr0, pl0);
-        if (g + 1 >= n_groups) break;
         const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
         p = p1 + group_bytes_dev<BITS>(L, nr1, pl1);
-        if (g + 2 < n_groups) {
-            h_cur = gh[g + 2];
-            issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
-        }
+        h_cur = gh[g + 2];
+        issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
         finish(rb, nr1, pl1);
+        g += 2;
+    }
+    if (g + 1 < n_groups) {  // two groups left: ra holds g
+        const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
+        const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
+        const uint32_t h1 = gh[g + 1];
+        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
+        finish(ra, nr0, pl0);
+        finish(rb, (int)(h1 & 0xffu), (int)(h1 >> 8));
+    } else if (g < n_groups) {
+        finish(ra, (int)(h_cur & 0xffu), (int)(h_cur >> 8));
     }
 #else
     for (uint32_t g = 0; g < n_groups; g += 2) {
@@ -344,6 +366,9 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     }
 
 #endif
+#ifdef MMG_DEBUG_TIMING
+    if (dbg && lane == 0) g_dbg[2] = wall_clock64();
+#endif
     if (MODE == MODE_SOR) {
         double s = 0.0;
         for (uint32_t i = lane; i < n_own; i += 64) {
@@ -356,6 +381,9 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
             if (lane == 0) a.partial[tile] = s;
         }
     }
+#ifdef MMG_DEBUG_TIMING
+    if (dbg && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_dbg[3] = wall_clock64(); }
+#endif
     if (MODE == MODE_RESID) {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
         // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan (residual_dev)

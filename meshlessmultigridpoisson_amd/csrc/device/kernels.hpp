@@ -54,6 +54,9 @@ struct TileArgs {
     int resid_lds;             // RESID over a level plan: keep r in LDS, write the own range back coalesced
 };
 
+#ifdef MMG_DEBUG_TIMING
+hipError_t debug_timing_get(unsigned long long *out8);  // development aid, see kernels.hip
+#endif
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
 // SOR phase with the tile's packed stream resident in LDS: one workgroup per tile, for phases of at
 // most a few tiles per CU (latency-bound small levels).  L = 2 / 4 plans with lds_bytes_resident <= LDS per CU.
