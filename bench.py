@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--force-dd", action="store_true",
                     help="take the domain-decomposition code path (slab-local system, RCCL communicator, exchange "
                          "lists) even with one rank -- rehearsal of the N>1 path on a 1-GPU box")
-    ap.add_argument("--slot-bits", type=int, default=16, choices=(12, 16),
+    ap.add_argument("--slot-bits", type=int, default=12, choices=(12, 16),
                     help="width of the tile-local column indices in the packed matrix stream (A/B)")
     ap.add_argument("--lds-resident", type=int, default=1,
                     help="0: off; 1: LDS-resident tile streams for phases of <= 1 tile per CU; k > 1: up to k tiles per CU (A/B)")

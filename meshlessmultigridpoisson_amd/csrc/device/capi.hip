@@ -27,11 +27,11 @@ namespace {
 thread_local std::string g_err;
 thread_local std::vector<hipEvent_t> *g_sweep_events = nullptr;  // mmg_level_time_phases: event pair per sweep-kernel launch
 bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created afterwards use the exact kernels
-// mmg_set_option("slot_bits", 12 | 16): LDS-slot width of level plans created afterwards.  12-bit slots cut the
-// packed stream from 571 to 539 B/row at K = 50 but measured 4-5 % SLOWER in three alternating same-box A/B
-// pairs (1125/1071/1075 vs 1086/1024/1016 us per sweep at 1e7 points): the sweep is not purely byte-bound,
-// the straddling decode costs more than the bytes save.  Kept as an option, default 16.
-int g_slot_bits = 16;
+// mmg_set_option("slot_bits", 12 | 16): width of the tile-local column indices of level plans created afterwards.
+// 12-bit slots cut the packed stream from 571 to 537 B/row at K = 50.  While every finish() still waited for the
+// prefetch it had just issued (see kernels.hip, group loop) they measured 4-5 % slower; with the join-free loop the
+// sweep is byte-bound again and they are 4-5 % faster (same box, 1e7 points, T = 1280: 81.3 / 81.4 vs 76.6 %).
+int g_slot_bits = 12;
 int g_resid_lds = 1;  // mmg_set_option("resid_lds", 0 | 1): residual rows leave a tile through LDS, coalesced
 int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident tile streams for the phases of small levels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
@@ -804,26 +804,25 @@ int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per
         }
     }
     if (!best) best = best_multi;
-    // Levels far larger than the device run as one dependency-driven launch
-    // (sweep_persistent_kernel): residency rounds do not matter there, larger tiles stage fewer
-    // halo values and wait on fewer neighbours, until fewer than 6 wavefronts fit a CU.
-    // Measured at 216^3, K = 50, L = 2 (same box): T 640 -> 72.9 %, 800 -> 78.5 %, 1000 -> 76.3 %,
-    // 1280 -> 72.9 % of 8 TB/s; 736 / 832 / 896 / 928 -> 67.6 / 68.6 / 69.8 / 69.0 % on a slower box.
+    // Levels far larger than the device run as one dependency-driven launch (sweep_persistent_kernel):
+    // residency rounds do not matter there, larger tiles stage fewer halo values and wait on fewer
+    // neighbours.  Measured at 216^3, K = 50, L = 2, 12-bit slots, join-free group loop (two boxes):
+    // T 896 -> 79.2 %, 1024 -> 82.6 / 81.5 / 72.5, 1152 -> 79.3, 1280 -> 84.6 / 81.4 / 81.3, 1408 -> 77.5,
+    // 1536 -> 75.2 / 75.2, 1792 -> 81.2 % of 8 TB/s: the largest multiple of 256 that keeps 4 wavefronts per CU.
+    // Mid-size levels are bound by the critical path of a sweep -- 8 phases x one tile's duration -- not by
+    // bandwidth, and small tiles keep that duration short: 171^3 = 5.0e6 points: T 256 / 384 / 640 / 896 ->
+    // 53.9 / 60.9 / 52.0 / 53.0 %; 190^3: 51.9 / 61.9 / - / 56.9 %; 160^3: 256 and 384 equal; at 128^3 256 is
+    // best, at 100^3 the sweep takes 0.40 ms whatever the tile.  The large tile pays from ~6 residency rounds on.
     if (L <= 2) {
         int big = 0;
-        for (int t = 256; t <= 2048; t += 32) {
+        for (int t = 256; t <= 2048; t += 256) {
             const double side = dim >= 3 ? std::cbrt((double)t) : std::sqrt((double)t);
             const double halo = std::pow(side + 2 * reach, dim >= 3 ? 3.0 : 2.0) - t;
             const double lds = (2.0 * t + halo + 1) * 8 + 256;
-            if (lds * 6 > 0.97 * lds_bytes_per_cu) break;
+            if (lds * 4 > 0.97 * lds_bytes_per_cu || t + halo + 1 > 4000) break;  // 4 wavefronts per CU, 12-bit slots
             big = t;
         }
-        // Mid-size levels are bound by the critical path of a sweep -- 8 phases x one tile's duration (~54 us
-        // at best) -- not by bandwidth, and small tiles keep that duration short: at 160^3 = 4.1e6 points
-        // T 256 -> 51.9 %, 384 -> 50.5 %, 640 -> 43.5 %, 896 -> 42.4 %; at 128^3 256 is best as well, at 100^3
-        // the sweep takes 0.43 ms whatever the tile.  The large tile pays once a sweep is 6+ residency rounds.
-        // 171^3 = 5.0e6: T 256 / 384 / 896 -> 52.4 / 55.2 / 49.4 %; 190^3 = 6.9e6: 51.9 / 61.9 / 56.9 %.
-        const double rounds_big = big > 0 ? (double)n_points / big / (6.0 * compute_units) : 0.0;
+        const double rounds_big = big > 0 ? (double)n_points / big / (4.0 * compute_units) : 0.0;
         if (big > best && rounds_big >= 6.0) best = big;
         else if (rounds_big >= 2.0) best = 384;
         else if (best > 256) best = 256;

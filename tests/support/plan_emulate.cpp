@@ -129,7 +129,7 @@ void run_plan(const Plan &P, int mode, double *x_inout, const double *in_other, 
 
 }  // namespace
 
-int g_slot_bits = 16;  // like libmmgp's default (mmg_set_option "slot_bits")
+int g_slot_bits = 12;  // like libmmgp's default (mmg_set_option "slot_bits")
 
 extern "C" {
 

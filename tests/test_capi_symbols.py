@@ -65,9 +65,9 @@ def test_host_library_loads_and_links_capi():
 
 def test_auto_tile_points_is_device_free_arithmetic():
     from meshlessmultigridpoisson_amd import _capi
-    # device-filling level: largest tile that keeps 6 wavefronts per CU (single dependency-driven launch)
-    assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 896
-    assert _capi.auto_tile_points(10077696, 3, 50, 0, 256, 163840) == 896  # lanes 0: as mmg_level_create picks L
+    # device-filling level: largest multiple of 256 that keeps 4 wavefronts per CU (single dependency-driven launch)
+    assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 1280
+    assert _capi.auto_tile_points(10077696, 3, 50, 0, 256, 163840) == 1280  # lanes 0: as mmg_level_create picks L
     assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 256  # one residency round per phase
     # mid-size levels are bound by 8 phases x one tile's duration: small tiles (measured 171^3, 190^3)
     assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 384

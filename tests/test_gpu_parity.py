@@ -386,7 +386,7 @@ def test_lds_resident_phase_kernel_and_12bit_slots_change_no_bit(name, tile, L):
             assert abs(d.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio(), key
     finally:
         _capi.set_option("lds_resident", 1)
-        _capi.set_option("slot_bits", 16)
+        _capi.set_option("slot_bits", 12)
         _capi.set_option("persistent_sweep", 1)
     for key in ("lds", "lds12", "plain12"):
         assert np.array_equal(xs[key], xs["plain"]), key
@@ -477,7 +477,7 @@ def test_lds_resident_phase_kernel_3d_k50():
             assert H.rel_err(xs[key], o.x) < 1e-12, key
     finally:
         _capi.set_option("lds_resident", 1)
-        _capi.set_option("slot_bits", 16)
+        _capi.set_option("slot_bits", 12)
         _capi.set_option("persistent_sweep", 1)
     for key in ("lds", "lds12", "single12"):
         assert np.array_equal(xs[key], xs["plain"]), key

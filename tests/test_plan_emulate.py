@@ -86,25 +86,27 @@ def test_explicit_zeros_are_dropped_but_multiplier_kept():
     assert nnz == expect
 
 
-def test_twelve_bit_slot_stream_option():
-    """mmg_set_option("slot_bits", 12): level plans with L = 2 / 4 and <= 4096 LDS slots per tile pack the
-    tile-local column indices in 12 bits (plan.hpp: slot_words): same rows, same entries, fewer stream bytes,
-    same arithmetic.  (Default stays 16: measured 4-5 % slower on the MI355X despite 5.6 % fewer bytes.)"""
+def test_twelve_bit_slot_stream_and_sixteen_bit_option():
+    """Level plans with L = 2 / 4 and <= 4096 LDS slots per tile pack the tile-local column indices in 12 bits
+    (plan.hpp: slot_words; the default); mmg_set_option("slot_bits", 16) keeps 16-bit slots.  Same rows, same
+    entries, fewer stream bytes, same arithmetic."""
     import ctypes
     case = H.load_case("dirichlet_3level")
     la = H.level_arrays(case, case["nlevels"] - 1)
     L = H.emu_lib()
     L.emu_level_slot_bits.argtypes = [ctypes.c_void_p]
-    e16 = H.EmuLevel(la, tile_size=64, lanes_per_row=2)
-    assert L.emu_level_slot_bits(e16.h) == 16
-    L.emu_set_slot_bits(12)
+    e12 = H.EmuLevel(la, tile_size=64, lanes_per_row=2)
+    assert L.emu_level_slot_bits(e12.h) == 12
+    e12n = H.EmuLevel(H.level_arrays(H.load_case("neumann_3level"), 2), tile_size=48, lanes_per_row=4)
+    assert L.emu_level_slot_bits(e12n.h) == 12
+    e8 = H.EmuLevel(la, tile_size=64, lanes_per_row=8)       # other lane counts keep 16-bit slots
+    assert L.emu_level_slot_bits(e8.h) == 16
+    L.emu_set_slot_bits(16)
     try:
-        e12 = H.EmuLevel(la, tile_size=64, lanes_per_row=2)
-        assert L.emu_level_slot_bits(e12.h) == 12
-        e12n = H.EmuLevel(H.level_arrays(H.load_case("neumann_3level"), 2), tile_size=48, lanes_per_row=4)
-        assert L.emu_level_slot_bits(e12n.h) == 12
+        e16 = H.EmuLevel(la, tile_size=64, lanes_per_row=2)
+        assert L.emu_level_slot_bits(e16.h) == 16
     finally:
-        L.emu_set_slot_bits(16)
+        L.emu_set_slot_bits(12)
     assert L.emu_level_nnz(e12.h) == L.emu_level_nnz(e16.h)
     assert L.emu_level_stream_bytes(e12.h) < L.emu_level_stream_bytes(e16.h)
     e12.sweeps(2)
