@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -252,7 +253,14 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         if (s.rows[k] < 0 || s.rows[k] >= A.rows) return "row id outside the matrix";
 
     std::vector<TileBuild> tb(s.n_tiles);
-    int nt = s.n_threads > 0 ? s.n_threads : (int)std::thread::hardware_concurrency();
+    // host threads of the plan packer: PlanSpec::n_threads, else MMG_NUM_THREADS, else all hardware threads
+    // (one process per GPU on an 8-GPU node: the launcher gives every rank its share, see bench.py)
+    int nt = s.n_threads;
+    if (nt <= 0) {
+        const char *e = std::getenv("MMG_NUM_THREADS");
+        nt = e ? std::atoi(e) : 0;
+    }
+    if (nt <= 0) nt = (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     nt = std::min(nt, s.n_tiles);
     std::atomic<int> next{0};

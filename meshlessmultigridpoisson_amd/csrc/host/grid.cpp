@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <thread>
 
@@ -83,7 +84,12 @@ Grid::~Grid()
 
 int Grid::threads() const
 {
-    int t = setup_threads_ > 0 ? setup_threads_ : (int)std::thread::hardware_concurrency();
+    int t = setup_threads_;
+    if (t <= 0) {  // MMG_NUM_THREADS: share of the host cores of this rank (one process per GPU)
+        const char *e = std::getenv("MMG_NUM_THREADS");
+        t = e ? std::atoi(e) : 0;
+    }
+    if (t <= 0) t = (int)std::thread::hardware_concurrency();
     return std::max(1, t);
 }
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <string>
@@ -457,7 +458,9 @@ void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, cons
             std::vector<int> ownedIdx;
             for (int i = 0; i < n; ++i) if (flags_in[i] != Grid::kGhost) ownedIdx.push_back(i);
             probe.kNearestNeighbors(pts[0], false, false, 1);
-            int nth = std::max(1u, std::thread::hardware_concurrency());
+            int nth = 0;
+            if (const char *e = std::getenv("MMG_NUM_THREADS")) nth = std::atoi(e);
+            if (nth <= 0) nth = (int)std::max(1u, std::thread::hardware_concurrency());
             std::atomic<size_t> next{0};
             std::vector<std::thread> th;
             for (int t = 0; t < nth; ++t)

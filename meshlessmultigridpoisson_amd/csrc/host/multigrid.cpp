@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <stdexcept>
@@ -73,7 +74,12 @@ Multigrid::SparseColMajor *Multigrid::buildInterpMatrix(Grid *base, Grid *target
     }
     std::vector<std::vector<double>> W((size_t)nt);
     std::vector<vector<int>> NB((size_t)nt);
-    int nth = base->setup_threads_ > 0 ? base->setup_threads_ : (int)std::thread::hardware_concurrency();
+    int nth = base->setup_threads_;
+    if (nth <= 0) {
+        const char *e = std::getenv("MMG_NUM_THREADS");
+        nth = e ? std::atoi(e) : 0;
+    }
+    if (nth <= 0) nth = (int)std::thread::hardware_concurrency();
     nth = std::max(1, std::min(nth, nt / 64 + 1));
     std::atomic<int> next{0};
     auto work = [&]() {
