@@ -55,6 +55,7 @@ def lib():
         L.mmgh_grid_get_boundaries.argtypes = [vp, _ip, _ip, _ip, _dp]
         L.mmgh_grid_get_tile_ptr.argtypes = [vp, _ip]
         L.mmgh_grid_get_tile_phase.argtypes = [vp, _ip]
+        L.mmgh_mg_setup_exchange.argtypes = [vp, C.c_int]
         for f in ("mmgh_grid_get_values", "mmgh_grid_get_source", "mmgh_grid_set_values", "mmgh_grid_set_source",
                   "mmgh_grid_residual", "mmgh_grid_residual_ratio"):
             getattr(L, f).argtypes = [vp, _dp]
@@ -252,6 +253,21 @@ class Grid:
         tp = np.zeros(s["n_tiles"] + 1, dtype=np.int32)
         lib().mmgh_grid_get_tile_ptr(self.h, tp.ctypes.data_as(_ip))
         return tp
+
+    def exchange_lists(self):
+        """(nbr, send_ptr, send_idx, recv_ptr) worked out by Multigrid::extract_subdomain in C++, or None."""
+        L = lib()
+        L.mmgh_grid_exchange_lists.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip, _ip]
+        sz = np.zeros(2, dtype=np.int32)
+        if L.mmgh_grid_exchange_lists(self.h, sz.ctypes.data_as(_ip), None, None, None, None) != 0:
+            return None
+        nbr = np.zeros(sz[0], dtype=np.int32)
+        sp = np.zeros(sz[0] + 1, dtype=np.int32)
+        si = np.zeros(max(sz[1], 1), dtype=np.int32)
+        rp = np.zeros(sz[0] + 1, dtype=np.int32)
+        L.mmgh_grid_exchange_lists(self.h, sz.ctypes.data_as(_ip), nbr.ctypes.data_as(_ip), sp.ctypes.data_as(_ip),
+                                   si.ctypes.data_as(_ip), rp.ctypes.data_as(_ip))
+        return nbr, sp, si[:sz[1]], rp
 
     def tile_phase(self):
         """Phase numbers (global tile colours) a sub-domain grid passes to libmmgp, or None."""
@@ -453,6 +469,11 @@ class Multigrid:
             lv.set_exchange(no, nbr, sp, si, rp)
             if exact:
                 lv.set_exchange_mode(1)
+
+    def setup_exchange_native(self, exact=False):
+        """The C++ path (Multigrid::setup_exchange): lists worked out by extract_subdomain from the global
+        hierarchy, no all_gather.  Needs mmg_comm_init."""
+        _chk(lib().mmgh_mg_setup_exchange(self.h, int(exact)))
 
     @property
     def nlevels(self):

@@ -563,6 +563,36 @@ vector<int> Grid::partition_slabs(int nparts)
     return part;
 }
 
+vector<std::pair<int, int>> Grid::ghost_list(const vector<int> &part, int rank, const vector<int> *extra_ghosts) const
+{
+    const int n = (int)points_.size();
+    if ((int)part.size() != n) throw std::invalid_argument("ghost_list: part size mismatch");
+    const int *rp = laplaceMat_->outerIndexPtr();
+    const int *col = laplaceMat_->innerIndexPtr();
+    vector<char> seen((size_t)n, 0);
+    vector<std::pair<int, int>> ghosts;
+    auto want = [&](int c) {
+        if (c < n && part[(size_t)c] != rank && !seen[(size_t)c]) { seen[(size_t)c] = 1; ghosts.emplace_back(part[(size_t)c], c); }
+    };
+    for (int i = 0; i < n; ++i)
+        if (part[(size_t)i] == rank)
+            for (int p = rp[i]; p < rp[i + 1]; ++p) want(col[p]);
+    if (extra_ghosts)
+        for (int c : *extra_ghosts) want(c);
+    std::sort(ghosts.begin(), ghosts.end());
+    return ghosts;
+}
+
+void Grid::setup_exchange(bool per_phase)
+{
+    if (nOwned_ < 0 || !exchange_.valid) throw std::runtime_error("Grid::setup_exchange: not a sub-domain built by Multigrid::extract_subdomain");
+    mmg_level *lv = device();
+    dev_check(mmg_level_set_exchange(lv, nOwned_, (int)exchange_.nbr.size(), exchange_.nbr.data(), exchange_.send_ptr.data(),
+                                     exchange_.send_idx.data(), exchange_.recv_ptr.data()),
+              "mmg_level_set_exchange");
+    if (per_phase) dev_check(mmg_level_set_exchange_mode(lv, 1), "mmg_level_set_exchange_mode");
+}
+
 Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts)
 {
     const int n = (int)points_.size();

@@ -117,6 +117,14 @@ public:
     // are kept as ghosts even if no owned row references them (transfer operators need them).
     // Neumann grids keep a replicated multiplier unknown (all-reduced on the device).
     Grid *extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr);
+    // The ghost list extract_subdomain(part, rank, extra_ghosts) would produce -- (owner, global index),
+    // sorted -- without building the sub-domain: lets every rank work out what its neighbours need from it.
+    vector<std::pair<int, int>> ghost_list(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr) const;
+    // Ghost refresh of this sub-domain level (mmg_level_set_exchange): neighbour ranks ascending, for each the
+    // local owned points it needs (send) and how many of this level's ghosts it owns (recv; ghosts are grouped
+    // by owner).  Filled by Multigrid::extract_subdomain; registered with the device by setup_exchange().
+    struct ExchangeLists { vector<int> nbr, send_ptr, send_idx, recv_ptr; bool valid = false; } exchange_;
+    void setup_exchange(bool per_phase = false);  // needs mmg_comm_init
 
     vector<Point> pointIDs_to_vector(const vector<int> &pointIDs);
     vector<int> kNearestNeighbors(Point point, bool neumannFlag, bool pointBCFlag, int k);  // grid.cpp:216-260

@@ -417,6 +417,24 @@ void *mmgh_mg_extract_subdomain(void *h, int nparts, int rank)
     if (guard([&]() { out = static_cast<Multigrid *>(h)->extract_subdomain(nparts, rank, nullptr); })) return nullptr;
     return out;
 }
+// exchange lists Multigrid::extract_subdomain worked out for level l (sizes first: out4 = n_nbr, n_send;
+// then the arrays when non-NULL)
+int mmgh_grid_exchange_lists(void *gp, int *out2, int *nbr, int *send_ptr, int *send_idx, int *recv_ptr)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    if (!g->exchange_.valid) return 1;
+    out2[0] = (int)g->exchange_.nbr.size();
+    out2[1] = (int)g->exchange_.send_idx.size();
+    if (nbr) std::memcpy(nbr, g->exchange_.nbr.data(), sizeof(int) * g->exchange_.nbr.size());
+    if (send_ptr) std::memcpy(send_ptr, g->exchange_.send_ptr.data(), sizeof(int) * g->exchange_.send_ptr.size());
+    if (send_idx) std::memcpy(send_idx, g->exchange_.send_idx.data(), sizeof(int) * g->exchange_.send_idx.size());
+    if (recv_ptr) std::memcpy(recv_ptr, g->exchange_.recv_ptr.data(), sizeof(int) * g->exchange_.recv_ptr.size());
+    return 0;
+}
+int mmgh_mg_setup_exchange(void *h, int per_phase)
+{
+    return guard([&]() { static_cast<Multigrid *>(h)->setup_exchange(per_phase != 0); });
+}
 void mmgh_mg_level_part(void *h, int l, int nparts, int *part)
 {
     auto p = static_cast<Multigrid *>(h)->grids_.at((size_t)l).second->partition_slabs(nparts);

@@ -193,17 +193,21 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     vector<vector<int>> part(nl);
     for (size_t l = 0; l < nl; ++l) part[l] = grids_[l].second->partition_slabs(nparts);
     // ghost needs of the transfers: columns (points of the INPUT level) touched by owned rows
-    vector<vector<int>> extra(nl);
-    auto need = [&](SparseColMajor *m, const vector<int> &row_part, vector<int> &dst) {
+    auto need = [&](SparseColMajor *m, const vector<int> &row_part, int q, vector<int> &dst) {
         if (!m) return;
         const int *cp = m->outerIndexPtr();
         const int *ri = m->innerIndexPtr();
         for (int j = 0; j < m->cols(); ++j)
             for (int p = cp[j]; p < cp[j + 1]; ++p)
-                if (row_part[(size_t)ri[p]] == rank) { dst.push_back(j); break; }
+                if (row_part[(size_t)ri[p]] == q) { dst.push_back(j); break; }
     };
-    for (size_t l = 1; l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], extra[l]);  // R_l : level l -> l-1
-    for (size_t l = 0; l + 1 < nl; ++l) need(prolongMatrices_[l], part[l + 1], extra[l]);  // P_l : level l -> l+1
+    auto extras_of = [&](int q) {
+        vector<vector<int>> ex(nl);
+        for (size_t l = 1; l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], q, ex[l]);  // R_l : level l -> l-1
+        for (size_t l = 0; l + 1 < nl; ++l) need(prolongMatrices_[l], part[l + 1], q, ex[l]);  // P_l : level l -> l+1
+        return ex;
+    };
+    vector<vector<int>> extra = extras_of(rank);
     Multigrid *out = fracStep_ ? new FractionalStepMultigrid() : new Multigrid();
     out->printResiduals_ = printResiduals_;
     vector<vector<int>> loc(nl);
@@ -230,8 +234,43 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     out->prolongMatrices_.assign(nl, nullptr);
     for (size_t l = 1; l < nl; ++l) out->restrictionMatrices_[l] = local_matrix(restrictionMatrices_[l], l - 1, l);
     for (size_t l = 0; l + 1 < nl; ++l) out->prolongMatrices_[l] = local_matrix(prolongMatrices_[l], l + 1, l);
+    // Exchange lists: the global hierarchy is known to every rank, so what a neighbour q needs from this rank
+    // is q's ghost list restricted to this rank's points -- no communication (the Python harness gathers the
+    // same lists with all_gather for the slab-local path, where no rank holds the global cloud).
+    {
+        vector<vector<vector<std::pair<int, int>>>> ghosts_of((size_t)nparts);  // [q][level]
+        for (int q = 0; q < nparts; ++q) {
+            const vector<vector<int>> ex = q == rank ? extra : extras_of(q);
+            ghosts_of[(size_t)q].resize(nl);
+            for (size_t l = 0; l < nl; ++l) ghosts_of[(size_t)q][l] = grids_[l].second->ghost_list(part[l], q, &ex[l]);
+        }
+        for (size_t l = 0; l < nl; ++l) {
+            Grid::ExchangeLists &x = out->grids_[l].second->exchange_;
+            x.send_ptr.assign(1, 0);
+            x.recv_ptr.assign(1, 0);
+            for (int q = 0; q < nparts; ++q) {
+                if (q == rank) continue;
+                int n_recv = 0;
+                for (const auto &g : ghosts_of[(size_t)rank][l]) n_recv += g.first == q;
+                vector<int> send;
+                for (const auto &g : ghosts_of[(size_t)q][l])
+                    if (g.first == rank) send.push_back(loc[l][(size_t)g.second]);
+                if (n_recv == 0 && send.empty()) continue;
+                x.nbr.push_back(q);
+                x.send_idx.insert(x.send_idx.end(), send.begin(), send.end());
+                x.send_ptr.push_back((int)x.send_idx.size());
+                x.recv_ptr.push_back(x.recv_ptr.back() + n_recv);
+            }
+            x.valid = true;
+        }
+    }
     if (parts_out) *parts_out = part;
     return out;
+}
+
+void Multigrid::setup_exchange(bool per_phase)
+{
+    for (auto &g : grids_) g.second->setup_exchange(per_phase);
 }
 
 double Multigrid::residual()

@@ -42,6 +42,10 @@ public:
     // operator AND the columns the local rows of R / P touch) and the local rows of the transfer
     // matrices.  parts_out[l] receives the owner of every global point of level l.
     Multigrid *extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out = nullptr);
+    // Multi-GPU run of a hierarchy returned by extract_subdomain (one process per GPU, mmg_comm_init done):
+    // registers every level's ghost exchange with the device -- the lists were worked out at extraction, from the
+    // global hierarchy every rank holds, without communication.  per_phase: exact mode (mmg_level_set_exchange_mode).
+    void setup_exchange(bool per_phase = false);
 
 protected:
     void ensure_device();

@@ -386,6 +386,13 @@ def test_distributed_vcycle_matches_hybrid_oracle(neumann):
             if rk.lists is None:
                 rk.lists = []
             rk.lists.append(lst)
+    # the lists the C++ classes work out without communication (Multigrid::extract_subdomain) are these lists
+    for l in range(mg.nlevels):
+        for r, (rk, sub) in enumerate(zip(ranks, subs)):
+            cpp = sub.grid(l).exchange_lists()
+            assert cpp is not None
+            for a, b in zip(cpp, rk.lists[l]):
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (l, r)
     for k in range(4):
         ro = om.vcycle_hybrid(parts, nparts)
         rd = _dist_vcycle(ranks)
