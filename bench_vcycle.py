@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--omega", type=float, default=1.4, help="SOR factor (reference default 1.4, testing_functions.cpp)")
     ap.add_argument("--iters", type=int, default=5, help="sweeps per smoothing call (reference default 5)")
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
-    ap.add_argument("--oracle-cycles", type=int, default=0, help="also run this many cycles on the CPU oracle")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
     _capi.set_option("persistent_sweep", a.persistent)
@@ -49,13 +48,6 @@ def main():
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
            "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
            "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
-    if a.oracle_cycles:
-        om = mg.oracle()  # state after the GPU cycles; compare the continuation
-        t0 = time.perf_counter()
-        ro = [om.vcycle() for _ in range(a.oracle_cycles)]
-        out["oracle_ms_per_vcycle"] = (time.perf_counter() - t0) / a.oracle_cycles * 1e3
-        rd = [mg.vcycle() for _ in range(a.oracle_cycles)]
-        out["max_rel_residual_diff_vs_oracle"] = float(max(abs(x - y) / y for x, y in zip(rd, ro)))
     print(json.dumps(out))
 
 

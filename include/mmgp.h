@@ -67,10 +67,14 @@ typedef struct {
     const int *tile_ptr;   /* [n_tiles+1] contiguous point ranges, one per tile */
     int n_tiles;
     int tile_size;         /* points per tile when tile_ptr is NULL             */
-    int lanes_per_row;     /* 1,2,4,8,16,32,64                                  */
+    int lanes_per_row;     /* 1,2,4,8,16                                        */
     const int *tile_phase; /* [n_tiles] or NULL: lower bound on the phase (stage of a sweep) of each tile;
                               sub-domains pass the GLOBAL tile colours so that every rank numbers its
                               phases alike (mmg_level_set_exchange_mode)        */
+    int waves_per_tile;    /* 0: automatic; 1: one wavefront per tile, packed stream (the streaming layout of
+                              levels far larger than the device); 2, 4, 8: dense layout, that many wavefronts
+                              share a tile and synchronise once per round of mutually uncoupled rows -- for
+                              levels whose sweep is bound by the dependency chain of a tile, not by bytes   */
 } mmg_level_desc;
 
 /* Introspection of the packed device layout (for DESIGN/bench reporting). */
@@ -85,6 +89,8 @@ typedef struct {
     long long stream_bytes;  /* packed bytes read per sweep (matrix stream)     */
     long long halo_entries;  /* ghost-of-tile values staged per sweep           */
     long long neumann_rows;
+    int waves_per_tile;      /* 1: packed stream, one wavefront per tile; > 1: dense layout */
+    int max_tile_levels;     /* longest dependency chain (levels of coupled rows) inside one tile */
 } mmg_level_info;
 
 const char *mmg_last_error(void);
@@ -94,6 +100,13 @@ int mmg_set_device(int device);
  * thread's handles; NULL selects the library's own non-blocking stream. */
 int mmg_set_stream(void *hip_stream);
 int mmg_synchronize(void);
+/* Event counters.  "sweep_fallbacks": how often a dependency-driven sweep launch (one launch per
+ * sweep / per smoothing call, see "persistent_sweep") could not make progress within its bounded
+ * waits -- e.g. because kernels of the host application occupied the compute units -- and the
+ * library restored x and repeated the sweeps (or the V-cycle body) with one launch per phase,
+ * which always progresses.  The affected level keeps per-phase launches afterwards.  Callers see
+ * no error: results are those of the reference's sequential sweep either way. */
+int mmg_get_counter(const char *name, long long *value);
 /* "persistent_sweep": 0 one launch per phase; 1 (default) automatic -- single launch when a
  * sweep needs more than one residency round of tiles; 4 always single launch; 2 single launch
  * with full agent-scope fences per tile (slow, for validation).  Single launch = resident
@@ -184,7 +197,11 @@ int mmg_level_set_exchange_mode(mmg_level *lv, int per_phase);
 int mmg_level_point_phases(mmg_level *lv, int *phase, int n);
 /* nbr_rank[n_nbr]; send_idx[send_ptr[k]..send_ptr[k+1]) = local indices of owned
  * points whose values neighbour k needs; ghosts received from neighbour k land at
- * x[n_owned_points + recv_ptr[k] .. n_owned_points + recv_ptr[k+1]). */
+ * x[n_owned_points + recv_ptr[k] .. n_owned_points + recv_ptr[k+1]).
+ * Collective once mmg_comm_init has created a communicator of more than one rank (every rank calls
+ * it for the same level in the same order): the ranks agree on whether ANY of them holds Neumann
+ * boundary rows on this level, so that the ghost refresh in front of bound_eval_neumann is issued by
+ * all ranks or by none (a sub-domain without boundary points still serves its neighbours). */
 int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const int *nbr_rank,
                            const int *send_ptr, const int *send_idx, const int *recv_ptr);
 int mmg_level_exchange(mmg_level *lv);

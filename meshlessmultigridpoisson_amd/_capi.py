@@ -24,13 +24,14 @@ class LevelDesc(C.Structure):
                 ("bcflags", _ip), ("neumann_flag", C.c_int), ("omega", C.c_double), ("iters", C.c_int),
                 ("nb", C.c_int), ("btype", _ip), ("bptr", _ip), ("bpts", _ip), ("bvals", _dp),
                 ("tile_ptr", _ip), ("n_tiles", C.c_int), ("tile_size", C.c_int), ("lanes_per_row", C.c_int),
-                ("tile_phase", _ip)]
+                ("tile_phase", _ip), ("waves_per_tile", C.c_int)]
 
 
 class LevelInfo(C.Structure):
     _fields_ = [("n_tiles", C.c_int), ("n_phases", C.c_int), ("n_groups", C.c_int), ("lanes_per_row", C.c_int),
                 ("max_lds_bytes", C.c_int), ("sor_rows", C.c_longlong), ("sor_nnz", C.c_longlong),
-                ("stream_bytes", C.c_longlong), ("halo_entries", C.c_longlong), ("neumann_rows", C.c_longlong)]
+                ("stream_bytes", C.c_longlong), ("halo_entries", C.c_longlong), ("neumann_rows", C.c_longlong),
+                ("waves_per_tile", C.c_int), ("max_tile_levels", C.c_int)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -39,7 +40,7 @@ class LevelInfo(C.Structure):
 #: every symbol include/mmgp.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mmg_last_error", "mmg_device_count", "mmg_set_device", "mmg_set_stream", "mmg_synchronize",
-    "mmg_device_props", "mmg_auto_tile_points", "mmg_set_option", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
+    "mmg_device_props", "mmg_auto_tile_points", "mmg_set_option", "mmg_get_counter", "mmg_comm_get_unique_id", "mmg_comm_init", "mmg_comm_finalize",
     "mmg_level_set_exchange", "mmg_level_set_exchange_mode", "mmg_level_point_phases", "mmg_level_exchange",
     "mmg_level_create", "mmg_level_destroy", "mmg_level_info_get", "mmg_level_set_x", "mmg_level_get_x",
     "mmg_level_set_rhs", "mmg_level_get_rhs", "mmg_level_set_bvals", "mmg_level_set_omega_iters",
@@ -152,6 +153,14 @@ def set_option(name, value):
     check(lib().mmg_set_option(name.encode(), int(value)))
 
 
+def get_counter(name):
+    v = C.c_longlong(0)
+    f = lib().mmg_get_counter
+    f.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
+    check(f(name.encode(), C.byref(v)))
+    return v.value
+
+
 def device_props():
     cu, lds = C.c_int(0), C.c_int(0)
     check(lib().mmg_device_props(C.byref(cu), C.byref(lds)))
@@ -196,7 +205,7 @@ def _pd(a):
 
 
 def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-              tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
+              tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None, waves_per_tile=0):
     """Returns (LevelDesc, keepalive) -- keepalive holds the numpy arrays."""
     keep = dict(rowptr=_i(rowptr), col=_i(col), val=_d(val), bcflags=_i(bcflags), btype=_i(btype),
                 bptr=_i(bptr), bpts=_i(bpts), bvals=_d(bvals))
@@ -220,6 +229,7 @@ def make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, 
         d.tile_phase = _pi(keep["tile_phase"])
     d.tile_size = int(tile_size)
     d.lanes_per_row = int(lanes_per_row)
+    d.waves_per_tile = int(waves_per_tile)
     return d, keep
 
 
@@ -236,9 +246,9 @@ class Level:
         return self
 
     def __init__(self, n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-                 x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
+                 x=None, b=None, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None, waves_per_tile=0):
         d, keep = make_desc(n, rowptr, col, val, bcflags, neumann, omega, iters, btype, bptr, bpts, bvals,
-                            tile_ptr, tile_size, lanes_per_row, tile_phase)
+                            tile_ptr, tile_size, lanes_per_row, tile_phase, waves_per_tile)
         self.n, self.a_size = d.n, d.a_size
         self.h = C.c_void_p()
         check(lib().mmg_level_create(C.byref(self.h), C.byref(d)))

@@ -405,13 +405,6 @@ class FracStepGrid(Grid):
         _chk(lib().mmgh_fs_residual(self.h, C.byref(v)))
         return v.value
 
-    def oracle(self):
-        """Oracle objects over the operators this grid built (tests only)."""
-        from oracle import oracle_c as oc
-        nx, ny = self.normals()
-        _bt, _bp, bpts, _bv = self.boundaries()
-        return oc.FracStep(self.sizes()["n"], self.op(0), self.op(1), self.op(2), nx, ny, bpts)
-
 
 class Multigrid:
     """Handle on a C++ `Multigrid` built by the reference's factory sequence."""
@@ -428,7 +421,7 @@ class Multigrid:
                                              abc.ctypes.data_as(_dp) if abc is not None else None, lanes_per_row)
         if not self.h:
             raise HostError(_err())
-        self.omega, self.iters = omega, iters
+        self.omega, self.iters, self.frac_step = omega, iters, bool(frac_step)
         self.residuals = []
 
     def __del__(self):
@@ -439,7 +432,7 @@ class Multigrid:
     @classmethod
     def _from_handle(cls, h, omega, iters):
         self = cls.__new__(cls)
-        self.h, self.omega, self.iters, self.residuals = h, omega, iters, []
+        self.h, self.omega, self.iters, self.residuals, self.frac_step = h, omega, iters, [], False
         return self
 
     def extract_subdomain(self, nparts, rank):
@@ -513,26 +506,6 @@ class Multigrid:
         v = C.c_double(0)
         _chk(lib().mmgh_mg_residual(self.h, C.byref(v)))
         return v.value
-
-    def oracle(self):
-        """The same hierarchy as CPU-oracle objects (tests / smoke / cpu_baseline only)."""
-        from oracle import oracle_c as oc
-        nl = self.nlevels
-        levels = []
-        for l in range(nl):
-            la = self.grid(l).level_arrays(self.omega, self.iters)
-            levels.append(oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"],
-                                   la["neumann"], la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"],
-                                   la["bvals"]))
-        R, P = [None] * nl, [None] * nl
-        for l in range(nl):
-            t = self.transfer("R", l)
-            if t:
-                R[l] = oc.Transfer.from_dict(t)
-            t = self.transfer("P", l)
-            if t:
-                P[l] = oc.Transfer.from_dict(t)
-        return oc.Multigrid(levels, R, P)
 
 
 # ---- synthetic clouds (vectorised; seeds per SURVEY 8d) ------------------------------------

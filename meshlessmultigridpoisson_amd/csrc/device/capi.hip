@@ -37,9 +37,13 @@ int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident 
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
 thread_local hipStream_t g_stream = nullptr;
 thread_local bool g_own_stream = false;
-// Error word of the dependency-driven kernels (a bounded wait ran out): one word in pinned, device-mapped
-// host memory, so every call that synchronises anyway can look at it for free.
+// Error word of the dependency-driven kernels (a bounded wait ran out, kernels.hip: wait_for_tiles): one
+// word in device memory, copied into a pinned host word in front of every synchronisation that settles a
+// level or a hierarchy (settle / settle_hierarchy below).
 unsigned *g_err_host = nullptr, *g_err_dev = nullptr;
+int g_waves = 0;  // mmg_set_option("waves_per_tile", n): layout of levels created afterwards whose descriptor says 0 -- 0 automatic, 1 packed stream, 2 / 4 / 8 dense
+int g_spin_bound = 1 << 22;        // mmg_set_option("debug_spin_bound", n): test hook, 0 makes every wait fail
+long long g_sweep_fallbacks = 0;   // mmg_get_counter("sweep_fallbacks")
 
 int fail(int code, const std::string &msg)
 {
@@ -64,9 +68,10 @@ int ensure_device()
         g_own_stream = true;
     }
     if (!g_err_host) {
-        HIPC(hipHostMalloc(reinterpret_cast<void **>(&g_err_host), sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
+        HIPC(hipHostMalloc(reinterpret_cast<void **>(&g_err_host), sizeof(unsigned), hipHostMallocPortable));
         *g_err_host = 0u;
-        HIPC(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_err_dev), g_err_host, 0));
+        HIPC(hipMalloc(reinterpret_cast<void **>(&g_err_dev), sizeof(unsigned)));
+        HIPC(hipMemset(g_err_dev, 0, sizeof(unsigned)));
     }
     return MMG_OK;
 }
@@ -162,6 +167,7 @@ struct PlanGpu {
     int n_tiles = 0;
     long long n_rows = 0, n_nnz = 0, n_groups = 0, stream_bytes = 0, halo_entries = 0;
     int max_lds = 0;
+    int max_levels = 0;
     bool exact = false;
     bool empty() const { return n_rows == 0; }
     int n_phases() const { return (int)phase_ptr.size() - 1; }
@@ -195,6 +201,10 @@ struct PlanGpu {
         dev.stream = stream.p;
         dev.phase_tiles = phase_tiles.p;
         dev.L = P.L;
+        dev.dense = P.dense ? 1 : 0;
+        dev.waves = P.waves;
+        max_levels = 0;
+        for (const TileDesc &t : P.tiles) max_levels = std::max(max_levels, (int)t.n_levels);
         dev.slot_bits = P.slot_bits;
         dev.n_tiles = P.n_tiles;
         dev.lds_bytes = (unsigned)P.lds_bytes();
@@ -206,6 +216,7 @@ struct PlanGpu {
 
 hipError_t run_tiles(const PlanGpu &pl, TileMode mode, const TileArgs &a, hipStream_t s)
 {
+    if (pl.dev.dense) return launch_tile_kernel_mw(mode, a, s);
     return pl.exact ? launch_tile_kernel_exact(mode, a, s) : launch_tile_kernel(mode, a, s);
 }
 
@@ -223,13 +234,12 @@ hipError_t run_sor_phase(const PlanGpu &pl, const TileArgs &a, hipStream_t s)
             lds_cu = (int)p.maxSharedMemoryPerMultiProcessor;
         } else cus = -1;
     }
-    const bool small = g_lds_resident && !pl.exact && cus > 0 && (pl.dev.L == 2 || pl.dev.L == 4) &&
+    if (pl.dev.dense) return launch_tile_kernel_mw(MODE_SOR, a, s);
+    const bool small = g_lds_resident && !pl.exact && cus > 0 && (pl.dev.L == 2 || pl.dev.L == 4 || pl.dev.L == 8 || pl.dev.L == 16) &&
                        pl.dev.lds_bytes_resident <= (unsigned)lds_cu && a.n_list <= (g_lds_resident > 1 ? g_lds_resident : 1) * cus;  // one workgroup per CU: a second round would cost what it saves
     if (small) return launch_tile_kernel_lds(a, s);
     return run_tiles(pl, MODE_SOR, a, s);
 }
-
-int pick_L(int L) { return L > 0 ? L : 4; }
 
 }  // namespace
 
@@ -257,6 +267,10 @@ struct mmg_level {
     int workers = 0;
     // domain decomposition (mmg_level_set_exchange)
     bool distributed = false;
+    // some rank of the communicator holds Neumann boundary rows on this level (agreed on collectively in
+    // mmg_level_set_exchange): bound_eval refreshes the ghosts on EVERY rank then, also on ranks whose own
+    // boundary plan is empty -- the grouped send/recv pairs up only if all ranks issue it
+    bool bound_exchange = false;
     // exact mode: ghosts refreshed before EVERY phase (mmg_level_set_exchange_mode), all ranks walk
     // `global_phases` phases in lockstep
     bool exchange_per_phase = false;
@@ -268,6 +282,11 @@ struct mmg_level {
     DevBuf<int32_t> send_idx;
     DevBuf<double> sendbuf;
     DevBuf<double> scalS;  // all-reduced sum of the non-Neumann x (multiplier row)
+    // recovery from a dependency-driven launch whose bounded wait ran out (settle)
+    DevBuf<double> x_backup;   // x in front of the unchecked sweeps
+    int unsettled_sweeps = 0;  // > 0: sweeps of the last mmg_level_sor / _sweeps call, issued but not yet checked
+    bool safe_mode = false;    // a dependency-driven launch failed once: one launch per phase from now on
+    bool in_cycle = false;     // inside vcycle_dev: the hierarchy does the checking (settle_hierarchy)
 };
 
 struct mmg_transfer {
@@ -282,6 +301,8 @@ struct mmg_hierarchy {
     std::vector<mmg_level *> lv;
     std::vector<mmg_transfer *> R, P;
     int frac_step = 0;
+    DevBuf<double> x_backup;  // fine-level x at the start of the unchecked cycle body
+    bool unsettled = false;   // the last cycle body used dependency-driven launches and has not been checked yet
 };
 
 struct mmg_fracstep {
@@ -338,6 +359,7 @@ int exchange_vec(mmg_level *lv, double *vec)
 // only costs (2-D 1e6-point V-cycle: 7.4 ms vs 5.8 ms), so "auto" keeps per-phase launches there.
 bool use_single_launch(const mmg_level *lv)
 {
+    if (lv->safe_mode) return false;
     if (lv->A.exact || lv->A.n_phases() <= 1 || lv->workers <= 0) return false;
     if (lv->distributed && lv->exchange_per_phase) return false;  // an exchange sits between the phases
     if (g_persistent_sweep == 0) return false;
@@ -359,10 +381,13 @@ bool use_resident_sweep(const mmg_level *lv)
             lds_cu = (int)p.maxSharedMemoryPerMultiProcessor;
         } else cus = -1;
     }
+    if (lv->safe_mode) return false;
     if (g_persistent_sweep != 1) return false;  // 0: strictly one launch per phase; 2, 4: the ticket kernel is forced
     if (g_lds_resident == 0 || g_lds_resident == 3 || cus <= 0 || lv->A.exact || lv->A.n_phases() <= 1) return false;  // 3: per-phase LDS kernel only (A/B)
     if (lv->distributed && lv->exchange_per_phase) return false;
-    if (!(lv->A.dev.L == 2 || lv->A.dev.L == 4) || !lv->sync_words.p) return false;
+    if (!(lv->A.dev.L == 2 || lv->A.dev.L == 4 || lv->A.dev.L == 8 || lv->A.dev.L == 16) || !lv->sync_words.p) return false;
+    // dense plans: several workgroups per CU may be resident together (lv->workers = occupancy x CUs)
+    if (lv->A.dev.dense) return lv->A.n_tiles <= lv->workers;
     return lv->A.n_tiles <= cus && lv->A.dev.lds_bytes_resident <= (unsigned)lds_cu;
 }
 
@@ -401,6 +426,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.n_list = lv->A.n_tiles;
         a.ticket = lv->sync_words.p;
         a.error = g_err_dev;
+        a.spin_bound = g_spin_bound;
         a.done = lv->sync_words.p + 2;
         const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
         const int ns = fusable ? std::min(k, 16) : 1;
@@ -408,6 +434,8 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.n_sweeps = ns;
         lv->epoch += (unsigned)ns;
         if ((erc = mark_event())) return erc;
+        if (lv->A.dev.dense) HIPC(launch_sweep_resident_mw(a, g_stream));
+        else
         HIPC(launch_sweep_resident(a, g_stream));
         if ((erc = mark_event())) return erc;
         *done = ns;
@@ -417,6 +445,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.n_list = lv->A.n_tiles;
         a.ticket = lv->sync_words.p;
         a.error = g_err_dev;
+        a.spin_bound = g_spin_bound;
         a.done = lv->sync_words.p + 2;
         // several sweeps per launch when nothing sits between them (no multiplier row, no Neumann
         // boundary solve, no ghost exchange): the queue simply runs over sweeps x tiles
@@ -428,6 +457,8 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.fence = g_persistent_sweep == 2;
         HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
         if ((erc = mark_event())) return erc;
+        if (lv->A.dev.dense) HIPC(launch_sweep_persistent_mw(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
+        else
         HIPC(launch_sweep_persistent(a, std::min(lv->workers, lv->A.n_tiles), g_stream));
         if ((erc = mark_event())) return erc;
         *done = ns;
@@ -467,30 +498,77 @@ int sweep_some(mmg_level *lv, int k, int *done)
     return MMG_OK;
 }
 
-// call after the stream has been synchronised
-int sync_error_seen()
+// ---- recovery from a failed dependency-driven launch -----------------------------------------
+// sweep_resident_kernel needs all its workgroups co-resident, sweep_persistent_kernel needs its ticket
+// holders to keep running; if something else occupies the CUs (kernels of the host application on the
+// stream handed to mmg_set_stream, another process), a bounded wait runs out, the kernel sets the device
+// error word and stops working.  The host looks at the word whenever it synchronises anyway; if it is
+// set, x is restored from the copy taken in front of the unchecked launches, the level drops to one
+// launch per phase for good (safe_mode; always makes progress) and the sweeps are repeated.  Callers
+// never see the event, except through mmg_get_counter("sweep_fallbacks").
+std::vector<mmg_level *> g_unsettled;  // levels with unchecked sweeps (mmg_synchronize settles them all)
+
+int sweeps(mmg_level *lv, int k);
+
+// Reads (and clears) the error word; synchronises the stream.  Ranks of a communicator agree on it.
+int read_error_word(bool distributed, bool *failed)
 {
-    if (g_err_host && *reinterpret_cast<volatile unsigned *>(g_err_host)) {
+    if (distributed && g_rccl.comm && g_rccl.nranks > 1)
+        NCCLC(g_rccl.AllReduce(g_err_dev, g_err_dev, 1, 3 /* ncclUint32 */, 2 /* ncclMax */, g_rccl.comm, g_stream));
+    HIPC(hipMemcpyAsync(g_err_host, g_err_dev, sizeof(unsigned), hipMemcpyDeviceToHost, g_stream));
+    HIPC(hipStreamSynchronize(g_stream));
+    *failed = *reinterpret_cast<volatile unsigned *>(g_err_host) != 0u;
+    if (*failed) {
+        HIPC(hipMemsetAsync(g_err_dev, 0, sizeof(unsigned), g_stream));
         *g_err_host = 0u;
-        return fail(MMG_ERR_HIP, "dependency-driven sweep: a tile's wait for its coupled tiles timed out (results invalid)");
     }
     return MMG_OK;
 }
 
-int check_sync_error(mmg_level *lv)
+bool multi_rank(const mmg_level *lv) { return lv->distributed && g_rccl.comm && g_rccl.nranks > 1; }
+
+// every entry point that reads or changes the state of a level passes here first
+int settle(mmg_level *lv)
 {
-    if (!lv->sync_words.p || lv->epoch == 0) return MMG_OK;
-    HIPC(hipStreamSynchronize(g_stream));
-    return sync_error_seen();
+    if (lv->unsettled_sweeps == 0) return MMG_OK;
+    const int k = lv->unsettled_sweeps;
+    lv->unsettled_sweeps = 0;
+    g_unsettled.erase(std::remove(g_unsettled.begin(), g_unsettled.end(), lv), g_unsettled.end());
+    bool failed = false;
+    int rc = read_error_word(lv->distributed, &failed);
+    if (rc || !failed) return rc;
+    ++g_sweep_fallbacks;
+    lv->safe_mode = true;
+    HIPC(hipMemcpyAsync(lv->x.p, lv->x_backup.p, sizeof(double) * (size_t)lv->a_size, hipMemcpyDeviceToDevice, g_stream));
+    return sweeps(lv, k);  // one launch per phase now: nothing left to check
+}
+
+int sweeps_unguarded(mmg_level *lv, int k);
+
+int sweeps(mmg_level *lv, int k)
+{
+    // ranks of a communicator must take the same decision: they all guard, whatever kernel each picks
+    const bool guarded = !lv->in_cycle && k > 0 && (use_resident_sweep(lv) || use_single_launch(lv) || (multi_rank(lv) && !lv->safe_mode));
+    if (!guarded) return sweeps_unguarded(lv, k);
+    int rc = settle(lv);  // at most one unchecked call per level
+    if (rc) return rc;
+    if (lv->x_backup.n != (size_t)lv->a_size) HIPC(lv->x_backup.alloc((size_t)lv->a_size));
+    HIPC(hipMemcpyAsync(lv->x_backup.p, lv->x.p, sizeof(double) * (size_t)lv->a_size, hipMemcpyDeviceToDevice, g_stream));
+    if ((rc = sweeps_unguarded(lv, k))) return rc;
+    lv->unsettled_sweeps = k;
+    g_unsettled.push_back(lv);
+    return MMG_OK;
 }
 
 int bound_eval(mmg_level *lv)
 {
-    if (lv->B.empty()) return MMG_OK;
-    if (lv->distributed) {  // Neumann rows read interior values owned by neighbours: current ones
+    // collective part first: the decision must not depend on rank-local state (a sub-domain without
+    // boundary points still serves its neighbours' Neumann rows)
+    if (lv->distributed && lv->bound_exchange) {  // Neumann rows read interior values owned by neighbours: current ones
         const int rc = exchange(lv);
         if (rc) return rc;
     }
+    if (lv->B.empty()) return MMG_OK;
     TileArgs a{};
     a.p = lv->B.dev;
     a.in = lv->x.p;
@@ -504,7 +582,7 @@ int bound_eval(mmg_level *lv)
     return MMG_OK;
 }
 
-int sweeps(mmg_level *lv, int k)
+int sweeps_unguarded(mmg_level *lv, int k)
 {
     for (int it = 0; it < k;) {
         int rc = exchange(lv);
@@ -569,15 +647,20 @@ int residual_dev(mmg_level *lv, bool norms)
     return MMG_OK;
 }
 
-int residual_ratio(mmg_level *lv, double *ratio)
+// *failed (optional): the device error word, read with the same synchronisation (vcycle_dev settles the
+// previous cycle body here, without a second host round trip)
+int residual_ratio(mmg_level *lv, double *ratio, bool *failed = nullptr)
 {
     int rc = residual_dev(lv, true);
     if (rc) return rc;
     double h[2];
     HIPC(hipMemcpyAsync(h, lv->scal.p, sizeof(h), hipMemcpyDeviceToHost, g_stream));
-    HIPC(hipStreamSynchronize(g_stream));
+    if (failed) {
+        if ((rc = read_error_word(lv->distributed, failed))) return rc;
+    } else
+        HIPC(hipStreamSynchronize(g_stream));
     *ratio = h[0] / h[1];
-    return sync_error_seen();  // every V-cycle passes here (residuals_.push_back): timed-out waits surface at once
+    return MMG_OK;
 }
 
 int boundary_op(mmg_level *lv, int coarse)
@@ -667,16 +750,12 @@ int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
     return MMG_OK;
 }
 
-int vcycle_dev(mmg_hierarchy *h, double *resid_before)
+// multigrid.cpp:68-109: everything of a V-cycle after the residual ratio
+int cycle_body(mmg_hierarchy *h)
 {
     const int nl = (int)h->lv.size();
     mmg_level *fine = h->lv[nl - 1];
     int rc;
-    if (h->frac_step && nl == 1) {  // FracStepMultigrid.cpp:64-67
-        *resid_before = -1.0;
-        return sweeps(fine, fine->iters);
-    }
-    if ((rc = residual_ratio(fine, resid_before))) return rc;  // multigrid.cpp:66
     if ((rc = bound_eval(fine))) return rc;                    // :68
     mmg_level *curr = fine;
     for (int i = nl - 1; i > 0; --i) {  // :71-88
@@ -697,6 +776,68 @@ int vcycle_dev(mmg_hierarchy *h, double *resid_before)
         if ((rc = sweeps(curr, curr->iters))) return rc;
     }
     return MMG_OK;
+}
+
+int run_cycle_body(mmg_hierarchy *h)
+{
+    for (mmg_level *l : h->lv) l->in_cycle = true;  // the hierarchy checks, not the levels
+    const int rc = cycle_body(h);
+    for (mmg_level *l : h->lv) l->in_cycle = false;
+    return rc;
+}
+
+// A cycle body whose dependency-driven launches failed is repeated from the fine-level x it started
+// from, with one launch per phase on every level (the coarse levels are rebuilt by the cycle itself:
+// x zeroed, b overwritten by the restriction).
+int repair_cycle(mmg_hierarchy *h)
+{
+    mmg_level *fine = h->lv.back();
+    ++g_sweep_fallbacks;
+    for (mmg_level *l : h->lv) l->safe_mode = true;
+    HIPC(hipMemcpyAsync(fine->x.p, h->x_backup.p, sizeof(double) * (size_t)fine->a_size, hipMemcpyDeviceToDevice, g_stream));
+    return run_cycle_body(h);
+}
+
+int settle_hierarchy(mmg_hierarchy *h)
+{
+    if (!h->unsettled) return MMG_OK;
+    h->unsettled = false;
+    bool failed = false;
+    const int rc = read_error_word(h->lv.back()->distributed, &failed);
+    if (rc || !failed) return rc;
+    return repair_cycle(h);
+}
+
+// final: check the cycle body before returning (mmg_vcycle); otherwise the check rides on the residual
+// synchronisation of the next cycle (mmg_vcycles: one host round trip per cycle, as before)
+int vcycle_dev(mmg_hierarchy *h, double *resid_before, bool final = true)
+{
+    const int nl = (int)h->lv.size();
+    mmg_level *fine = h->lv[nl - 1];
+    int rc;
+    for (mmg_level *l : h->lv)
+        if ((rc = settle(l))) return rc;  // sweeps issued through the level API
+    if (h->frac_step && nl == 1) {  // FracStepMultigrid.cpp:64-67
+        *resid_before = -1.0;
+        return sweeps(fine, fine->iters);
+    }
+    bool failed = false;
+    if ((rc = residual_ratio(fine, resid_before, &failed))) return rc;  // multigrid.cpp:66
+    if (failed && h->unsettled) {  // the previous cycle body: repeat it, then this cycle's ratio
+        h->unsettled = false;
+        if ((rc = repair_cycle(h))) return rc;
+        if ((rc = residual_ratio(fine, resid_before))) return rc;
+    }
+    h->unsettled = false;
+    bool guarded = false;
+    for (mmg_level *l : h->lv) guarded = guarded || use_resident_sweep(l) || use_single_launch(l) || (multi_rank(l) && !l->safe_mode);
+    if (guarded) {
+        if (h->x_backup.n != (size_t)fine->a_size) HIPC(h->x_backup.alloc((size_t)fine->a_size));
+        HIPC(hipMemcpyAsync(h->x_backup.p, fine->x.p, sizeof(double) * (size_t)fine->a_size, hipMemcpyDeviceToDevice, g_stream));
+    }
+    if ((rc = run_cycle_body(h))) return rc;
+    h->unsettled = guarded;
+    return final ? settle_hierarchy(h) : MMG_OK;
 }
 
 }  // namespace
@@ -739,6 +880,8 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "slot_bits") == 0) { g_slot_bits = value == 12 ? 12 : 16; return MMG_OK; }
     if (std::strcmp(name, "lds_resident") == 0) { g_lds_resident = value; return MMG_OK; }
     if (std::strcmp(name, "resid_lds") == 0) { g_resid_lds = value != 0; return MMG_OK; }
+    if (std::strcmp(name, "waves_per_tile") == 0) { g_waves = value; return MMG_OK; }
+    if (std::strcmp(name, "debug_spin_bound") == 0) { g_spin_bound = value < 0 ? (1 << 22) : value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -749,12 +892,28 @@ int mmg_debug_timing(unsigned long long *out8)
     HIPC(mmg::debug_timing_get(out8));
     return MMG_OK;
 }
+int mmg_debug_timing_tiles(unsigned long long *out, int n_tiles, int dense)
+{
+    HIPC(hipStreamSynchronize(g_stream));
+    if (dense) HIPC(mmg::debug_timing_tiles_mw_get(out, n_tiles));
+    else HIPC(mmg::debug_timing_tiles_get(out, n_tiles));
+    return MMG_OK;
+}
 #endif
+
+int mmg_get_counter(const char *name, long long *value)
+{
+    if (!name || !value) return fail(MMG_ERR_INVALID, "null argument");
+    if (std::strcmp(name, "sweep_fallbacks") == 0) { *value = g_sweep_fallbacks; return MMG_OK; }
+    return fail(MMG_ERR_INVALID, std::string("unknown counter ") + name);
+}
 
 int mmg_synchronize(void)
 {
     int rc = ensure_device();
     if (rc) return rc;
+    while (!g_unsettled.empty())
+        if ((rc = settle(g_unsettled.back()))) return rc;
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;
 }
@@ -772,9 +931,27 @@ int mmg_device_props(int *compute_units, int *lds_bytes_per_cu)
     return MMG_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Dense multi-wavefront layout or packed stream?  A sweep over the packed stream costs at least
+// phases x (one tile's dependency chain) ~ phases x 35 us however small the level; the dense layout runs the
+// chain ~5x faster but moves ~1.3x the bytes.  Dense wins while its bytes stream in less time than the
+// packed chain takes (3-D K = 50: below ~2e6 points; 2-D K = 37: below ~1.4e6).
+bool level_is_latency_bound(long long n_points, double avg_row_len)
+{
+    const double phases = avg_row_len >= 44.0 ? 8.0 : 4.0;  // 3-D / 2-D tile colourings of Grid::mc_order_points
+    const double dense_bytes = (double)n_points * (12.0 * avg_row_len + 28.0) * 1.3;
+    return dense_bytes / 6.0e12 < phases * 35e-6;
+}
+}  // namespace
+
+extern "C" {
+
 int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per_row, int compute_units,
                          int lds_bytes_per_cu)
 {
+    if (g_waves != 1 && (g_waves > 1 || level_is_latency_bound(n_points, (double)stencil))) return 256;  // dense layout: short chains, many tiles
     if (compute_units <= 0 || lds_bytes_per_cu <= 0) {
         compute_units = 256;       // MI355X
         lds_bytes_per_cu = 163840;
@@ -879,7 +1056,11 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
     {
         Plan P;
-        const std::string err = build_level_plan(*d, L, &P, g_exact, g_slot_bits);
+        const double avg_row = (double)d->rowptr[d->n] / std::max(1, d->n);
+        int waves = d->waves_per_tile > 0 ? d->waves_per_tile : g_waves;
+        if (waves <= 0) waves = level_is_latency_bound(d->n, avg_row) ? 4 : 1;
+        if (!(waves == 1 || waves == 2 || waves == 4 || waves == 8)) return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 4 or 8");
+        const std::string err = build_level_plan(*d, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;
         if ((rc = lv->A.upload(P))) return rc;
@@ -917,6 +1098,8 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
         hipDeviceProp_t prop;
         HIPC(hipGetDevice(&dev));
         HIPC(hipGetDeviceProperties(&prop, dev));
+        if (lv->A.dev.dense) HIPC(sweep_persistent_mw_blocks_per_cu(lv->A.dev, &per_cu));
+        else
         HIPC(sweep_persistent_blocks_per_cu(lv->A.dev, &per_cu));
         lv->workers = per_cu * prop.multiProcessorCount;
     }
@@ -927,7 +1110,11 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     return MMG_OK;
 }
 
-void mmg_level_destroy(mmg_level *lv) { delete lv; }
+void mmg_level_destroy(mmg_level *lv)
+{
+    if (lv) g_unsettled.erase(std::remove(g_unsettled.begin(), g_unsettled.end(), lv), g_unsettled.end());
+    delete lv;
+}
 
 int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info)
 {
@@ -942,6 +1129,8 @@ int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info)
     info->stream_bytes = lv->A.stream_bytes;
     info->halo_entries = lv->A.halo_entries;
     info->neumann_rows = lv->B.n_rows;
+    info->waves_per_tile = lv->A.dev.dense ? lv->A.dev.waves : 1;
+    info->max_tile_levels = lv->A.max_levels;
     return MMG_OK;
 }
 
@@ -950,7 +1139,8 @@ int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info)
     {                                                                                                \
         if (!lv || !v || count != lv->a_size) return fail(MMG_ERR_INVALID, #name ": bad size");      \
         int rc = ensure_device();                                                                    \
-        if (rc) return rc;
+        if (rc) return rc;                                                                           \
+        if ((rc = settle(lv))) return rc;
 
 LEVEL_VEC_IO(mmg_level_set_x, x, const)
     HIPC(hipMemcpyAsync(lv->x.p, v, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g_stream));
@@ -958,7 +1148,6 @@ LEVEL_VEC_IO(mmg_level_set_x, x, const)
     return MMG_OK;
 }
 LEVEL_VEC_IO(mmg_level_get_x, x, )
-    if ((rc = check_sync_error(lv))) return rc;
     HIPC(hipMemcpyAsync(v, lv->x.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;
@@ -984,6 +1173,7 @@ int mmg_level_set_bvals(mmg_level *lv, const double *bvals, int count)
 int mmg_level_set_omega_iters(mmg_level *lv, double omega, int iters)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     lv->omega = omega;
     lv->iters = iters;
     return MMG_OK;
@@ -1002,11 +1192,13 @@ int mmg_level_sweeps(mmg_level *lv, int nsweeps)
 int mmg_level_bound_eval_neumann(mmg_level *lv)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     return bound_eval(lv);
 }
 int mmg_level_residual(mmg_level *lv, double *r_out, int count)
 {
     if (!lv || (r_out && count != lv->a_size)) return fail(MMG_ERR_INVALID, "residual: bad size");
+    if (int src_ = settle(lv)) return src_;
     int rc = residual_dev(lv, false);
     if (rc) return rc;
     if (r_out) {
@@ -1018,21 +1210,25 @@ int mmg_level_residual(mmg_level *lv, double *r_out, int count)
 int mmg_level_residual_ratio(mmg_level *lv, double *ratio)
 {
     if (!lv || !ratio) return fail(MMG_ERR_INVALID, "null argument");
+    if (int src_ = settle(lv)) return src_;
     return residual_ratio(lv, ratio);
 }
 int mmg_level_boundary_op(mmg_level *lv, int coarse)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     return boundary_op(lv, coarse);
 }
 int mmg_level_modify_coeff_neumann(mmg_level *lv, int coarse)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     return modify_coeff_neumann(lv, coarse);
 }
 int mmg_level_zero_x(mmg_level *lv)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     HIPC(launch_fill(lv->x.p, lv->a_size, 0.0, g_stream));
     return MMG_OK;
 }
@@ -1050,6 +1246,7 @@ int mmg_level_time_sweeps(mmg_level *lv, int nsweeps, int reps, float *ms_out)
         HIPC(hipEventRecord(e1, g_stream));
         HIPC(hipEventSynchronize(e1));
         HIPC(hipEventElapsedTime(&ms_out[r], e0, e1));
+        if (!rc) rc = settle(lv);
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1077,12 +1274,13 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
     if (rc) return rc;
     *kernel_ms = (float)sum;
     *launches = (int)(ev.size() / 2);
-    return check_sync_error(lv);
+    return settle(lv);
 }
 
 int mmg_level_time_residual(mmg_level *lv, int reps, float *ms_out)
 {
     if (!lv || !ms_out || reps < 1) return fail(MMG_ERR_INVALID, "bad argument");
+    if (int src_ = settle(lv)) return src_;
     hipEvent_t e0, e1;
     HIPC(hipEventCreate(&e0));
     HIPC(hipEventCreate(&e1));
@@ -1140,6 +1338,7 @@ int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const i
 {
     if (!lv || n_owned_points < 0 || n_owned_points > lv->n || n_nbr < 0) return fail(MMG_ERR_INVALID, "set_exchange: bad argument");
     if (lv->A.exact) return fail(MMG_ERR_UNSUPPORTED, "exact_arithmetic levels cannot be distributed");
+    if (int src_ = settle(lv)) return src_;
     if (n_nbr > 0 && (!nbr_rank || !send_ptr || !recv_ptr)) return fail(MMG_ERR_INVALID, "set_exchange: null lists");
     lv->nbr.assign(nbr_rank, nbr_rank + n_nbr);
     lv->send_ptr.assign(send_ptr, send_ptr + (n_nbr ? n_nbr + 1 : 0));
@@ -1153,12 +1352,23 @@ int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const i
     HIPC(lv->scalS.alloc(1));
     lv->n_owned = n_owned_points;
     lv->distributed = true;
+    // collective when a communicator of more than one rank exists: does ANY rank hold Neumann rows here?
+    double any_b = lv->B.empty() ? 0.0 : 1.0;
+    if (g_rccl.comm && g_rccl.nranks > 1) {
+        DevBuf<double> d;
+        HIPC(d.upload(&any_b, 1));
+        NCCLC(g_rccl.AllReduce(d.p, d.p, 1, kNcclDouble, 2 /* ncclMax */, g_rccl.comm, g_stream));
+        HIPC(hipMemcpyAsync(&any_b, d.p, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+    }
+    lv->bound_exchange = any_b > 0.0;
     return MMG_OK;
 }
 
 int mmg_level_set_exchange_mode(mmg_level *lv, int per_phase)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "set_exchange_mode: null level");
+    if (int src_ = settle(lv)) return src_;
     if (!per_phase) { lv->exchange_per_phase = false; return MMG_OK; }
     if (!lv->distributed) return fail(MMG_ERR_INVALID, "set_exchange_mode: mmg_level_set_exchange has not been called");
     if (lv->point_phase.size() != (size_t)lv->n)
@@ -1206,6 +1416,7 @@ int mmg_level_point_phases(mmg_level *lv, int *phase, int n)
 int mmg_level_exchange(mmg_level *lv)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
     return exchange(lv);
 }
 
@@ -1243,11 +1454,15 @@ void mmg_transfer_destroy(mmg_transfer *t) { delete t; }
 int mmg_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
 {
     if (!fine || !coarse || !R) return fail(MMG_ERR_INVALID, "null argument");
+    int rc = settle(fine);
+    if (rc || (rc = settle(coarse))) return rc;
     return do_restrict(fine, coarse, R);
 }
 int mmg_prolong_add(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
 {
     if (!fine || !coarse || !P) return fail(MMG_ERR_INVALID, "null argument");
+    int rc = settle(fine);
+    if (rc || (rc = settle(coarse))) return rc;
     return do_prolong(coarse, fine, P);
 }
 
@@ -1281,6 +1496,8 @@ int mmg_vcycle(mmg_hierarchy *h, double *resid_before)
 int mmg_hierarchy_residual(mmg_hierarchy *h, double *ratio)
 {
     if (!h || !ratio) return fail(MMG_ERR_INVALID, "null argument");
+    int rc = settle_hierarchy(h);
+    if (rc || (rc = settle(h->lv.back()))) return rc;
     return residual_ratio(h->lv.back(), ratio);
 }
 int mmg_vcycles(mmg_hierarchy *h, int ncycles, double *resid, float *ms)
@@ -1293,7 +1510,7 @@ int mmg_vcycles(mmg_hierarchy *h, int ncycles, double *resid, float *ms)
     int rc = MMG_OK;
     for (int c = 0; c < ncycles && !rc; ++c) {
         double r = 0.0;
-        rc = vcycle_dev(h, &r);
+        rc = vcycle_dev(h, &r, c == ncycles - 1);
         if (resid) resid[c] = r;
     }
     HIPC(hipEventRecord(e1, g_stream));
@@ -1485,6 +1702,7 @@ int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho)
 {
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
+    if ((rc = settle(fs->p))) return rc;
     if ((rc = fs_apply(fs->dx, fs->w[2].p, fs->t1.p))) return rc;
     if ((rc = fs_apply(fs->dy, fs->w[3].p, fs->t2.p))) return rc;
     HIPC(launch_fs_ppe_interior(fs->p->b.p, fs->t1.p, fs->t2.p, rho / dt, fs->n, g_stream));
@@ -1497,6 +1715,7 @@ int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho)
 {
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
+    if ((rc = settle(fs->p))) return rc;
     if ((rc = fs_apply(fs->dx, fs->p->x.p, fs->t1.p))) return rc;
     HIPC(launch_fs_correct(fs->w[0].p, fs->w[2].p, fs->t1.p, dt / rho, fs->n, g_stream));
     if ((rc = fs_apply(fs->dy, fs->p->x.p, fs->t2.p))) return rc;

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "tile_common.hpp"
 
 namespace mmg {
 
@@ -20,38 +21,17 @@ namespace mmg {
 // per-phase SOR launch: [0] entry [1] inputs staged [2] groups done [3] own range written [4] groups [5] tile
 __device__ unsigned long long g_dbg[8];
 hipError_t debug_timing_get(unsigned long long *out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg), sizeof(g_dbg)); }
+// per-tile stamps of every SOR tile (tile < kDbgTiles): [0] tile entered [1] inputs staged [2] groups done [3] written back
+constexpr int kDbgTiles = 1 << 16;
+__device__ unsigned long long g_dbg_tiles[kDbgTiles * 4];
+hipError_t debug_timing_tiles_get(unsigned long long *out, int n_tiles)
+{
+    if (n_tiles > kDbgTiles) n_tiles = kDbgTiles;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_tiles), sizeof(unsigned long long) * 4 * (size_t)n_tiles);
+}
 #endif
 
 namespace {
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// cross-lane add inside groups of L lanes, DPP (no LDS traffic) up to L = 16
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double v)
-{
-    const unsigned long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
-    return v + __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-template <int L>
-__device__ __forceinline__ double row_sum(double v)
-{
-    if (L >= 2) v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]  : lane ^ 1
-    if (L >= 4) v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]  : lane ^ 2
-    if (L >= 8) v = dpp_add<0x141>(v);   // row_half_mirror      : other quad of the 8
-    if (L >= 16) v = dpp_add<0x140>(v);  // row_mirror           : other half of the 16
-    if (L >= 32) v += __shfl_xor(v, 16, 64);
-    if (L >= 64) v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 __device__ __forceinline__ size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // 8-byte words of the slot section per lane (plan.hpp: slot_words)
@@ -75,45 +55,52 @@ struct GroupRegs {
     uint2 s[NS];
     RowMeta m;
     double d;
+    uint32_t head;  // rows | entries-per-lane << 8 of the group these registers belong to (wave-uniform)
 };
 
-// Issue every global load of one group (no waits): the stream address depends on
-// nothing but the group heads, so the next group's loads fly while the current
-// group is gathered and reduced.
+// Issue every load of one group (no waits): the stream address depends on nothing but the group
+// heads, so the loads of the next group(s) fly while the current group is gathered and reduced.
+// Entries q >= plen of the register set are loaded from a block of zeros (`zeros`: >= 512 B, global
+// memory) by a SCALAR select of the base address -- no per-entry masking is left for finish().
+// NT = false: the stream lies in LDS (tile_kernel_lds / sweep_resident_kernel): plain ds_reads, the
+// index is clamped and the value masked instead (no LDS-resident block of zeros).
 template <int L, int MAXP, int BITS, bool NT = true>
-__device__ __forceinline__ void issue_group(const unsigned char *p, int nr, int plen, int lane, GroupRegs<MAXP, BITS> &r)
+__device__ __forceinline__ void issue_group(const unsigned char *p, uint32_t head, int lane, const double *zeros,
+                                            GroupRegs<MAXP, BITS> &r)
 {
+    const int nr = (int)(head & 0xffu), plen = (int)(head >> 8);
     const int W = nr * L;
-    // lanes beyond W re-read lane W-1's data (always in bounds); they are masked in finish()
+    // lanes beyond W re-read lane W-1's data (always in bounds); their rows do not exist, finish() drops them
     const int ln = lane < W ? lane : W - 1;
-    const double *vals = reinterpret_cast<const double *>(p + 16 * nr) + ln;
-    const uint2 *sl = reinterpret_cast<const uint2 *>(p + 16 * nr + al16((size_t)plen * W * 8)) + ln;
+    const double *vals = reinterpret_cast<const double *>(p + 16 * nr);
+    const uint2 *sl = reinterpret_cast<const uint2 *>(p + 16 * nr + al16((size_t)plen * W * 8));
     const int plen4 = slot_words_dev<BITS>(plen);
     constexpr int NS = GroupRegs<MAXP, BITS>::NS;
-#ifndef MMG_PLAIN_STREAM  // non-temporal policy on the read-once matrix stream: +5 % at 1e7 points (L2/MALL keep the x halo lines)
-    if (!NT) {  // stream already resident in LDS (tile_kernel_lds): plain ds_reads
+    r.head = head;
+    if (!NT) {
 #pragma unroll
-        for (int q4 = 0; q4 < NS; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
+        for (int q4 = 0; q4 < NS; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W + ln];
 #pragma unroll
-        for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
+        for (int q = 0; q < MAXP; ++q) {
+            const double v = vals[(q < plen ? q : plen - 1) * W + ln];
+            r.v[q] = q < plen ? v : 0.0;
+        }
     } else {
+        // non-temporal policy on the read-once matrix stream: +5 % at 1e7 points (L2/MALL keep the x halo lines)
 #pragma unroll
-    for (int q4 = 0; q4 < NS; ++q4) {
-        const unsigned long long w = __builtin_nontemporal_load(
-            reinterpret_cast<const unsigned long long *>(sl + (q4 < plen4 ? q4 : plen4 - 1) * W));
-        r.s[q4] = make_uint2((unsigned)(w & 0xffffffffull), (unsigned)(w >> 32));
+        for (int q4 = 0; q4 < NS; ++q4) {
+            const unsigned long long w = __builtin_nontemporal_load(
+                reinterpret_cast<const unsigned long long *>(sl + (q4 < plen4 ? q4 : plen4 - 1) * W) + ln);
+            r.s[q4] = make_uint2((unsigned)(w & 0xffffffffull), (unsigned)(w >> 32));
+        }
+#pragma unroll
+        for (int q = 0; q < MAXP; ++q) {
+            const double *src = q < plen ? vals + q * W : zeros;  // wave-uniform: an s_cselect on the base
+            r.v[q] = __builtin_nontemporal_load(src + ln);
+        }
     }
-#pragma unroll
-    for (int q = 0; q < MAXP; ++q) r.v[q] = __builtin_nontemporal_load(vals + (q < plen ? q : plen - 1) * W);
-    }
-#else
-#pragma unroll
-    for (int q4 = 0; q4 < NS; ++q4) r.s[q4] = sl[(q4 < plen4 ? q4 : plen4 - 1) * W];
-#pragma unroll
-    for (int q = 0; q < MAXP; ++q) r.v[q] = vals[(q < plen ? q : plen - 1) * W];
-#endif
     if (BITS == 12) {
-        // Entries q >= plen are masked by their value (0), but their slot must still be a valid LDS index:
+        // Entries q >= plen carry the value 0, but their slot must still be a valid LDS index:
         // 0 * (whatever lies beyond the tile's slots) may be NaN.  With 16-bit slots a re-read word holds
         // valid slots; a 12-bit window over re-read words does not, so words past the group's own are zeroed
         // (slot 0; bits past 12*plen inside the last own word are zero in the packed stream).
@@ -143,25 +130,9 @@ __device__ __forceinline__ unsigned slot_at(const uint2 (&s)[NS], int q)
     return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-// x accesses of the dependency-driven sweep go through agent-scope relaxed atomics
-// (global_load/store ... sc1): L2-served, never stale in another CU's L1
-// (MI355X_MICROARCH "Workgroup dispatch ... inter-workgroup visibility").
-template <bool SC1>
-__device__ __forceinline__ double ld_x(const double *p)
-{
-    if (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool SC1>
-__device__ __forceinline__ void st_x(double *p, double v)
-{
-    if (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
 // One wavefront per tile.  LDS: xs[n_slots] (inputs) | bs[n_own] (rhs of the own
 // range, SOR/RESID) | gh[n_groups] (group heads).
-template <int L, int MODE, int MAXP, bool SC1, int BITS, bool LDSS = false>
+template <int L, int MODE, int MAXP, bool SC1, int BITS, bool LDSS = false, int DEPTH = 2>
 __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, unsigned char *smem, const double lam,
                                              const bool load_stream = true)
 {
@@ -170,6 +141,8 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 #ifdef MMG_DEBUG_TIMING
     const bool dbg = MODE == MODE_SOR && !SC1 && blockIdx.x == 8;
     if (dbg && lane == 0) g_dbg[0] = wall_clock64();
+    const bool dbt = MODE == MODE_SOR && tile < kDbgTiles && lane == 0;
+    if (dbt) g_dbg_tiles[tile * 4 + 0] = wall_clock64();
 #endif
     const TileDesc td = a.p.tiles[tile];
     const uint32_t n_own = td.n_own, n_halo = td.n_halo, n_groups = td.n_groups;
@@ -266,42 +239,74 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         __syncthreads();
         p = smem + lds_stream_off;
     }
-    GroupRegs<MAXP, BITS> ra, rb;
-    uint32_t h_cur = n_groups ? ghg[0] : 0;  // first head straight from global: no LDS round trip
-    if (n_groups) issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
+    // ---- group pipeline: DEPTH register sets, DEPTH-1 groups in flight ahead of the one being reduced ----
+    // The issue front runs DEPTH-1 groups ahead and is CLAMPED to the last group: every issue below is
+    // unconditional (near the end of the tile the last group is simply requested again, from cache), so no
+    // control-flow join sits between an issue and a finish() and the compiler's s_waitcnt counts stay exact
+    // (vmcnt = the loads issued after the set being consumed).  With a conditional issue the merged wait state
+    // was vmcnt(3): every finish() waited for the prefetch it had just issued (ISA, round 1g).
+    GroupRegs<MAXP, BITS> r[DEPTH];
+    uint32_t gi = 0;                        // group at the issue front
+    const unsigned char *pi = p;            // its packed bytes
+    uint32_t hi = n_groups ? ghg[0] : 0;    // its head; the first DEPTH-1 heads come straight from global (scalar loads)
+    if (n_groups) {
+#pragma unroll
+        for (int j = 0; j < DEPTH - 1; ++j) {
+            issue_group<L, MAXP, BITS, !LDSS>(pi, hi, lane, a.zeros, r[j]);
+            const bool more = gi + 1 < n_groups;
+            pi += more ? group_bytes_dev<BITS>(L, (int)(hi & 0xffu), (int)(hi >> 8)) : 0;
+            gi += more ? 1u : 0u;
+            hi = ghg[gi];
+        }
+    }
     __syncthreads();
 
 #ifdef MMG_DEBUG_TIMING
     if (dbg && lane == 0) { g_dbg[1] = wall_clock64(); g_dbg[4] = n_groups; g_dbg[5] = (unsigned long long)tile; }
+    if (dbt) g_dbg_tiles[tile * 4 + 1] = wall_clock64();
 #endif
     const int sub = lane & (L - 1);
     double local = 0.0;  // RESID: sum |r|
 
-    auto finish = [&](const GroupRegs<MAXP, BITS> &r, int nr, int plen) {
-        const int W = nr * L;
-        double acc = 0.0;
+    auto finish = [&](const GroupRegs<MAXP, BITS> &g) {
+        const int W = (int)(g.head & 0xffu) * L;
+        // All LDS gathers of the group are issued before the first FMA (left alone the scheduler interleaves
+        // them in batches of 4 with a full lgkmcnt(0) drain each: ~120 cycles per entry on a latency-bound
+        // level, measured 1.3 us per 25-entry group with one wavefront per SIMD); two accumulators halve
+        // the dependent FMA chain.
+        double acc0 = 0.0, acc1 = 0.0;
+        constexpr int CH = MAXP <= 32 ? MAXP : 32;  // chunks bound the registers of the wide-row instantiations
 #pragma unroll
-        for (int q = 0; q < MAXP; ++q) {
-            const double v = (q < plen && lane < W) ? r.v[q] : 0.0;
-            acc = fma(v, xs[slot_at<BITS>(r.s, q)], acc);
+        for (int q0 = 0; q0 < MAXP; q0 += CH) {
+            double xv[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (q0 + q < MAXP) xv[q] = xs[slot_at<BITS>(g.s, q0 + q)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (q0 + q < MAXP) {
+                    if (q & 1) acc1 = fma(g.v[q0 + q], xv[q], acc1);
+                    else acc0 = fma(g.v[q0 + q], xv[q], acc0);
+                }
         }
-        acc = row_sum<L>(acc);
+        double acc = row_sum<L>(acc0 + acc1);
         if (lane < W && sub == 0) {
-            const RowMeta m = r.m;
+            const RowMeta m = g.m;
             if (MODE == MODE_SOR) {
                 double xi = bs[m.self] - acc;
                 if (m.flags & 1) xi -= lam;
-                xi *= a.omega / r.d;
+                xi *= a.omega / g.d;
                 xi += (1.0 - a.omega) * xs[m.self];
                 xs[m.self] = xi;
             } else if (MODE == MODE_BOUND) {
                 const double bi = (m.self < n_own) ? bs[m.self] : a.b[m.gid];
-                const double xi = (bi - acc) / r.d;
+                const double xi = (bi - acc) / g.d;
                 a.out[m.gid] = xi;
                 if (m.self != kNoSlot) xs[m.self] = xi;
             } else if (MODE == MODE_RESID) {
                 const double bi = (m.self < n_own) ? bs[m.self] : a.b[m.gid];
-                double rr = bi - (acc + r.d * xs[m.self]);
+                double rr = bi - (acc + g.d * xs[m.self]);
                 if (m.flags & 1) rr -= lam;
                 // level plans: the row's rhs slot is dead now, r goes there and leaves the tile in one
                 // coalesced pass (scattered 8-byte stores otherwise)
@@ -316,58 +321,28 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
         }
     };
 
-    // Two groups per trip so the register sets alternate without copies.
-#ifndef MMG_UNCOND_ISSUE
-    // Steady state: while two more groups exist both issues are unconditional, so no control-flow join sits
-    // between an issue and the finish() of the group before it -- the compiler's s_waitcnt then counts
-    // exactly (vmcnt = the loads of the group just issued) and the loads of group g+1 really fly while
-    // group g is reduced.  With `if (g + 1 < n_groups) issue(...)` inside the loop the merged wait state
-    // was vmcnt(3): every finish() waited for the prefetch it had just issued (ISA, round 1g; in-kernel
-    // stamps: 1.9 us per group on a latency-bound level, 1.3 us even with the stream in LDS).
-    uint32_t g = 0;
-    while (g + 2 < n_groups) {
-        const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
-        const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
-        const uint32_t h1 = gh[g + 1];
-        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-        finish(ra, nr0, pl0);
-        const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
-        p = p1 + group_bytes_dev<BITS>(L, nr1, pl1);
-        h_cur = gh[g + 2];
-        issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
-        finish(rb, nr1, pl1);
-        g += 2;
+    if (n_groups) hi = gh[gi];  // from here on the heads come from LDS
+    // Full trips of DEPTH groups: one back edge, no exit inside (an early exit makes the compiler route all
+    // exits through a shared latch whose merged wait state drains the pipeline once per trip).  The last
+    // n_groups % DEPTH groups are in flight when the loop ends (issue front clamped): finished without issues.
+    const uint32_t n_main = n_groups / DEPTH, n_rem = n_groups - n_main * DEPTH;
+    for (uint32_t t = 0; t < n_main; ++t) {
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            issue_group<L, MAXP, BITS, !LDSS>(pi, hi, lane, a.zeros, r[(j + DEPTH - 1) % DEPTH]);
+            const bool more = gi + 1 < n_groups;
+            pi += more ? group_bytes_dev<BITS>(L, (int)(hi & 0xffu), (int)(hi >> 8)) : 0;
+            gi += more ? 1u : 0u;
+            hi = gh[gi];
+            finish(r[j]);
+        }
     }
-    if (g + 1 < n_groups) {  // two groups left: ra holds g
-        const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
-        const unsigned char *p1 = p + group_bytes_dev<BITS>(L, nr0, pl0);
-        const uint32_t h1 = gh[g + 1];
-        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-        finish(ra, nr0, pl0);
-        finish(rb, (int)(h1 & 0xffu), (int)(h1 >> 8));
-    } else if (g < n_groups) {
-        finish(ra, (int)(h_cur & 0xffu), (int)(h_cur >> 8));
-    }
-#else
-    for (uint32_t g = 0; g < n_groups; g += 2) {
-        const int nr0 = (int)(h_cur & 0xffu), pl0 = (int)(h_cur >> 8);
-        const bool has1 = g + 1 < n_groups;
-        const unsigned char *p1 = has1 ? p + group_bytes_dev<BITS>(L, nr0, pl0) : p;
-        const uint32_t h1 = has1 ? gh[g + 1] : h_cur;
-        issue_group<L, MAXP, BITS, !LDSS>(p1, (int)(h1 & 0xffu), (int)(h1 >> 8), lane, rb);
-        finish(ra, nr0, pl0);
-        if (!has1) break;
-        const int nr1 = (int)(h1 & 0xffu), pl1 = (int)(h1 >> 8);
-        const bool has2 = g + 2 < n_groups;
-        p = has2 ? p1 + group_bytes_dev<BITS>(L, nr1, pl1) : p1;
-        h_cur = has2 ? gh[g + 2] : h1;
-        issue_group<L, MAXP, BITS, !LDSS>(p, (int)(h_cur & 0xffu), (int)(h_cur >> 8), lane, ra);
-        finish(rb, nr1, pl1);
-    }
-
-#endif
+#pragma unroll
+    for (int j = 0; j < DEPTH - 1; ++j)
+        if ((uint32_t)j < n_rem) finish(r[j]);
 #ifdef MMG_DEBUG_TIMING
     if (dbg && lane == 0) g_dbg[2] = wall_clock64();
+    if (dbt) g_dbg_tiles[tile * 4 + 2] = wall_clock64();
 #endif
     if (MODE == MODE_SOR) {
         double s = 0.0;
@@ -383,6 +358,7 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     }
 #ifdef MMG_DEBUG_TIMING
     if (dbg && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_dbg[3] = wall_clock64(); }
+    if (dbt) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_dbg_tiles[tile * 4 + 3] = wall_clock64(); }
 #endif
     if (MODE == MODE_RESID) {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
@@ -403,6 +379,13 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     }
 }
 
+// Register sets of the group pipeline.  A wavefront tracks at most 63 outstanding vector-memory
+// instructions; a group is MAXP + NS + 2 of them: 36 for the long 3-D rows at 2 lanes per row (two sets, the
+// streaming configuration of the large levels), 21 at MAXP = 16 (three sets), 12 at MAXP = 8 (four sets) -- the
+// short-row configurations of the latency-bound levels, where one group ahead does not cover a memory latency.
+template <int MAXP>
+constexpr int kDepth = MAXP <= 8 ? 4 : (MAXP <= 16 ? 3 : 2);
+
 template <int L, int MODE, int MAXP, int BITS>
 __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
 {
@@ -417,7 +400,7 @@ __global__ __launch_bounds__(64) void tile_kernel(TileArgs a)
     double lam = 0.0;
     if (MODE == MODE_SOR || MODE == MODE_RESID)
         if (a.lambda) lam = *a.lambda;
-    process_tile<L, MODE, MAXP, false, BITS>(a, tile, smem, lam);
+    process_tile<L, MODE, MAXP, false, BITS, false, kDepth<MAXP>>(a, tile, smem, lam);
 }
 
 // Latency-optimised sweep phase for SMALL levels (at most a few tiles per CU): one workgroup per
@@ -455,26 +438,12 @@ __global__ __launch_bounds__(64) void sweep_resident_kernel(TileArgs a)
         const unsigned want_now = a.epoch + (unsigned)sw;       // earlier coupled tiles: this sweep done
         const unsigned want_prev = a.epoch + (unsigned)sw - 1;  // later coupled tiles: previous sweep done
         const int l1 = sw > 0 ? l1e : l0;
-        const int n_wait = (d1 - d0) + (l1 - l0);
-        for (int base = 0; base < n_wait; base += 64) {
-            const int k = base + lane;
-            const bool mine = k < n_wait;
-            const bool early = k < (d1 - d0);
-            const int dep = !mine ? tile : (early ? a.p.dep_idx[d0 + k] : a.p.later_idx[l0 + (k - (d1 - d0))]);
-            const unsigned need = early ? want_now : want_prev;
-            const unsigned *flag = a.done + dep;
-            bool ok = !mine;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (!ok) ok = (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (!__all(ok) && lane == 0) *reinterpret_cast<volatile unsigned *>(a.error) = 1u;  // pinned host word
-        }
+        const bool ok = wait_for_tiles<2>(a, tile, d0, d1, l0, l1, want_now, want_prev);
         // x goes through agent-scope (sc1) accesses as in sweep_persistent_kernel; the matrix stream is
-        // read-only and lands in LDS once (sw == 0)
-        process_tile<L, MODE_SOR, MAXP, true, BITS, true>(a, tile, smem, lam, sw == 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // read-only and lands in LDS once (sw == 0).  After a failed wait (anywhere in the grid) the results
+        // of this launch are discarded by the host: no more work, only the flags, so that everyone drains fast.
+        if (ok) process_tile<L, MODE_SOR, MAXP, true, BITS, true>(a, tile, smem, lam, sw == 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // x stores have reached L2; also a compiler barrier
         if (lane == 0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
@@ -485,9 +454,14 @@ __global__ __launch_bounds__(64) void sweep_resident_kernel(TileArgs a)
 // is coupled to have published their x values, so the ramp-up, the tail and the input
 // staging of consecutive phases overlap instead of being separated by kernel boundaries.
 // Progress: a ticket holder only waits for tiles with smaller tickets, whose holders are
-// running -- no co-residency requirement, no grid barrier.  Visibility: x is written with
-// sc1 stores, drained (vmcnt(0)), released at agent scope, then the tile's flag is stored;
-// the consumer polls relaxed, acquires once at agent scope, and reads x with sc1 loads.
+// running -- no co-residency requirement, no grid barrier.  Visibility (FENCE = false, the default):
+// every x access of this kernel is a relaxed agent-scope atomic (global_load/store ... sc1: served by
+// L2, never by a CU's L1), the producer drains its x stores (s_waitcnt vmcnt(0): the stores have been
+// acknowledged by L2) and then stores the flag with an sc1 store; the consumer polls the flag with sc1
+// loads and issues its x loads afterwards (in-order issue per wavefront; `asm volatile(... "memory")`
+// and __atomic_signal_fence keep the compiler from moving them across).  No acquire/release cache
+// maintenance is executed: nothing that matters is ever cached outside L2.  FENCE = true adds the
+// generic agent-scope fences (1.6x slower, same bits).
 template <int L, int MAXP, bool FENCE, int BITS>
 __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
 {
@@ -508,23 +482,7 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
         const unsigned want_prev = a.epoch + sw - 1;  // later coupled tiles: previous sweep done
         const int d0 = a.p.dep_ptr[tile], d1 = a.p.dep_ptr[tile + 1];
         const int l0 = a.p.later_ptr[tile], l1 = sw > 0 ? a.p.later_ptr[tile + 1] : a.p.later_ptr[tile];
-        const int n_wait = (d1 - d0) + (l1 - l0);
-        for (int base = 0; base < n_wait; base += 64) {
-            const int k = base + lane;
-            const bool mine = k < n_wait;
-            const bool early = k < (d1 - d0);
-            const int dep = !mine ? tile : (early ? a.p.dep_idx[d0 + k] : a.p.later_idx[l0 + (k - (d1 - d0))]);
-            const unsigned need = early ? want_now : want_prev;
-            const unsigned *flag = a.done + dep;
-            bool ok = !mine;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                // flags only grow; unsigned difference handles wrap-around
-                if (!ok) ok = (int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - need) >= 0;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (!__all(ok) && lane == 0) *reinterpret_cast<volatile unsigned *>(a.error) = 1u;  // pinned host word  // never hang: report and go on
-        }
+        const bool ok = wait_for_tiles<8>(a, tile, d0, d1, l0, l1, want_now, want_prev);
         // Every access to x in this kernel is an sc1 (agent-scope) load or store, the stores
         // are drained before the flag is published and the flag is polled with sc1 loads: the
         // hand-off needs no cache maintenance.  FENCE adds the full agent-scope acquire/release
@@ -534,7 +492,8 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        process_tile<L, MODE_SOR, MAXP, true, BITS>(a, tile, smem, lam);
+        // after a failed wait (here or anywhere in the grid) the host discards this launch: only the flags from here on
+        if (ok) process_tile<L, MODE_SOR, MAXP, true, BITS, false, kDepth<MAXP>>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (FENCE) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -545,9 +504,9 @@ __global__ __launch_bounds__(64) void sweep_persistent_kernel(TileArgs a)
     }
 }
 
-// 12-bit slot streams exist for level plans only (SOR / RESID, L = 2 or 4: level_plan.cpp)
+// 12-bit slot streams exist for level plans only (SOR / RESID, L = 2 ... 16: level_plan.cpp)
 template <int L>
-constexpr bool kHas12 = (L == 2 || L == 4);
+constexpr bool kHas12 = (L == 2 || L == 4 || L == 8 || L == 16);
 
 template <int L, int MAXP>
 hipError_t launch_LP(TileMode mode, const TileArgs &a, hipStream_t s)
@@ -957,16 +916,27 @@ hipError_t launch_sum_partials(const double *partial, int n, double *out, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s)
+// >= 512 B of zeros in global memory: source of the register entries past a group's length (issue_group)
+static const double *zeros_block()
 {
+    static double *z = nullptr;
+    if (!z) {
+        if (hipMalloc(reinterpret_cast<void **>(&z), 1024) != hipSuccess) return nullptr;
+        (void)hipMemset(z, 0, 1024);
+    }
+    return z;
+}
+
+hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a0, hipStream_t s)
+{
+    TileArgs a = a0;
+    if (!(a.zeros = zeros_block())) return hipErrorOutOfMemory;
     switch (a.p.L) {
     case 1: return launch_L<1>(mode, a, s);
     case 2: return launch_L<2>(mode, a, s);
     case 4: return launch_L<4>(mode, a, s);
     case 8: return launch_L<8>(mode, a, s);
     case 16: return launch_L<16>(mode, a, s);
-    case 32: return launch_L<32>(mode, a, s);
-    case 64: return launch_L<64>(mode, a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -994,13 +964,17 @@ hipError_t launch_lds_LB(const TileArgs &a, hipStream_t s)
     if (mp <= 64) return launch_lds_LPB<L, 64, BITS>(a, s);
     return hipErrorInvalidValue;
 }
-// SOR phase of a small level, L = 2 or 4 only (the lanes-per-row values level plans pick)
-hipError_t launch_tile_kernel_lds(const TileArgs &a, hipStream_t s)
+// SOR phase of a small level, L = 2 ... 16 (the lanes-per-row values level plans pick)
+hipError_t launch_tile_kernel_lds(const TileArgs &a0, hipStream_t s)
 {
+    TileArgs a = a0;
+    if (!(a.zeros = zeros_block())) return hipErrorOutOfMemory;
     if (a.n_list <= 0) return hipSuccess;
     const bool b12 = a.p.slot_bits == 12;
     if (a.p.L == 2) return b12 ? launch_lds_LB<2, 12>(a, s) : launch_lds_LB<2, 16>(a, s);
     if (a.p.L == 4) return b12 ? launch_lds_LB<4, 12>(a, s) : launch_lds_LB<4, 16>(a, s);
+    if (a.p.L == 8) return b12 ? launch_lds_LB<8, 12>(a, s) : launch_lds_LB<8, 16>(a, s);
+    if (a.p.L == 16) return b12 ? launch_lds_LB<16, 12>(a, s) : launch_lds_LB<16, 16>(a, s);
     return hipErrorInvalidValue;
 }
 
@@ -1029,12 +1003,16 @@ hipError_t launch_res_LB(const TileArgs &a, hipStream_t s)
 }
 // all phases (and a.n_sweeps fused sweeps) of a level whose tiles are all resident at once;
 // the caller guarantees a.n_list <= compute units and lds_bytes_resident <= LDS per CU
-hipError_t launch_sweep_resident(const TileArgs &a, hipStream_t s)
+hipError_t launch_sweep_resident(const TileArgs &a0, hipStream_t s)
 {
+    TileArgs a = a0;
+    if (!(a.zeros = zeros_block())) return hipErrorOutOfMemory;
     if (a.n_list <= 0) return hipSuccess;
     const bool b12 = a.p.slot_bits == 12;
     if (a.p.L == 2) return b12 ? launch_res_LB<2, 12>(a, s) : launch_res_LB<2, 16>(a, s);
     if (a.p.L == 4) return b12 ? launch_res_LB<4, 12>(a, s) : launch_res_LB<4, 16>(a, s);
+    if (a.p.L == 8) return b12 ? launch_res_LB<8, 12>(a, s) : launch_res_LB<8, 16>(a, s);
+    if (a.p.L == 16) return b12 ? launch_res_LB<16, 12>(a, s) : launch_res_LB<16, 16>(a, s);
     return hipErrorInvalidValue;
 }
 
@@ -1065,8 +1043,6 @@ hipError_t sweep_persistent_blocks_per_cu(const PlanDev &p, int *blocks)
     case 4: return occ_L<4>(p, blocks);
     case 8: return occ_L<8>(p, blocks);
     case 16: return occ_L<16>(p, blocks);
-    case 32: return occ_L<32>(p, blocks);
-    case 64: return occ_L<64>(p, blocks);
     }
     return hipErrorInvalidValue;
 }
@@ -1098,8 +1074,10 @@ hipError_t launch_norms_exact(double *r, const double *b, const double *x, const
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_persistent(const TileArgs &a, int workers, hipStream_t s)
+hipError_t launch_sweep_persistent(const TileArgs &a0, int workers, hipStream_t s)
 {
+    TileArgs a = a0;
+    if (!(a.zeros = zeros_block())) return hipErrorOutOfMemory;
     if (a.n_list <= 0 || workers <= 0) return hipSuccess;
     switch (a.p.L) {
     case 1: return launch_persist_L<1>(a, workers, s);
@@ -1107,8 +1085,6 @@ hipError_t launch_sweep_persistent(const TileArgs &a, int workers, hipStream_t s
     case 4: return launch_persist_L<4>(a, workers, s);
     case 8: return launch_persist_L<8>(a, workers, s);
     case 16: return launch_persist_L<16>(a, workers, s);
-    case 32: return launch_persist_L<32>(a, workers, s);
-    case 64: return launch_persist_L<64>(a, workers, s);
     }
     return hipErrorInvalidValue;
 }

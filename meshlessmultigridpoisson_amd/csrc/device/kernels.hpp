@@ -13,6 +13,8 @@ struct PlanDev {
     const uint8_t *stream = nullptr;
     const int32_t *phase_tiles = nullptr;
     int L = 4;
+    int dense = 0;       // Plan::dense: fixed-shape groups, `waves` wavefronts per tile (kernels_mw.hip)
+    int waves = 1;
     int slot_bits = 16;  // Plan::slot_bits
     int n_tiles = 0;
     unsigned lds_bytes = 0;
@@ -49,13 +51,17 @@ struct TileArgs {
     unsigned *done;            // per tile: epoch of the last completed sweep
     unsigned epoch;            // value a tile publishes after its FIRST sweep of this launch
     int n_sweeps;              // sweeps fused into this launch (tickets run over n_sweeps * n_list)
-    unsigned *error;           // set (plain store of 1; pinned, device-mapped host word) when a dependency wait times out
+    unsigned *error;           // device word, set to 1 when a dependency wait runs out of polls (wait_for_tiles)
+    int spin_bound;            // polls per dependency wait (default 1 << 22; option "debug_spin_bound")
     int fence;                 // 1: add agent-scope acquire/release fences around every tile
     int resid_lds;             // RESID over a level plan: keep r in LDS, write the own range back coalesced
+    const double *zeros;       // >= 512 B of zeros in global memory (set by the launch wrappers)
 };
 
 #ifdef MMG_DEBUG_TIMING
 hipError_t debug_timing_get(unsigned long long *out8);  // development aid, see kernels.hip
+hipError_t debug_timing_tiles_get(unsigned long long *out, int n_tiles);
+hipError_t debug_timing_tiles_mw_get(unsigned long long *out, int n_tiles);
 #endif
 hipError_t launch_tile_kernel(TileMode mode, const TileArgs &a, hipStream_t s);
 // SOR phase with the tile's packed stream resident in LDS: one workgroup per tile, for phases of at
@@ -71,6 +77,15 @@ hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_
 hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, hipStream_t s);
 hipError_t launch_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
                               int a_size, double *out2, hipStream_t s);
+
+// ---- dense plans (PlanDev::dense): workgroups of PlanDev::waves wavefronts per tile (kernels_mw.hip) ----
+// one phase of a sweep (MODE_SOR) or the residual (MODE_RESID)
+hipError_t launch_tile_kernel_mw(TileMode mode, const TileArgs &a, hipStream_t s);
+// every phase and a.n_sweeps fused sweeps of a level whose tiles are all resident at once (one workgroup per tile)
+hipError_t launch_sweep_resident_mw(const TileArgs &a, hipStream_t s);
+// dependency-driven single launch with `workers` resident workgroups
+hipError_t launch_sweep_persistent_mw(const TileArgs &a, int workers, hipStream_t s);
+hipError_t sweep_persistent_mw_blocks_per_cu(const PlanDev &p, int *blocks);
 
 // one launch per sweep: `workers` resident wavefronts pull tiles in phase order and wait
 // for their coupled earlier tiles through agent-scope flags

@@ -11,7 +11,7 @@ int widen_L(const CsrView &A, const int32_t *rows, int64_t n_rows, int L)
 {
     int maxlen = 0;
     for (int64_t k = 0; k < n_rows; ++k) maxlen = std::max(maxlen, A.rowptr[rows[k] + 1] - A.rowptr[rows[k]]);
-    while (L < 64 && (maxlen + L - 1) / L > 64) L *= 2;
+    while (L < 16 && (maxlen + L - 1) / L > 64) L *= 2;  // kernels exist for 1 ... 16 lanes per row
     return L;
 }
 }  // namespace
@@ -44,8 +44,21 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
     return err;
 }
 
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits)
+int dense_lanes(int lanes_per_row, double avg_row_len)
 {
+    if (lanes_per_row == 4 || lanes_per_row == 8 || lanes_per_row == 16) return lanes_per_row;
+    return avg_row_len >= 44.0 ? 16 : 8;
+}
+
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits, int waves)
+{
+    if (waves > 1 && !exact) {  // dense layout first; rows too long for it -> the packed layout below
+        const int Ld = dense_lanes(d.lanes_per_row, (double)d.rowptr[d.n] / std::max(1, d.n));
+        const std::string derr = build_level_plan(d, Ld, out, false, 16, -waves);
+        if (derr.rfind("rows-too-long-for-dense", 0) != 0) return derr;
+        waves = 1;
+    }
+    const int dense_waves = waves < -1 ? -waves : 0;
     const int n = d.n;
     CsrView A{d.a_size, d.a_size, d.rowptr, d.col, d.val};
     std::vector<int32_t> pt_tile;
@@ -67,7 +80,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         if (d.bcflags[i] == 0) rows.push_back(i);
     if (!rows.empty() && rows.back() >= pt_tile.back()) return "an interior row lies outside every tile";
     std::string err;
-    L = exact ? 1 : widen_L(A, rows.data(), (int64_t)rows.size(), L);
+    L = exact ? 1 : (dense_waves ? L : widen_L(A, rows.data(), (int64_t)rows.size(), L));
     for (int attempt = 0; attempt < 10; ++attempt) {
         const int nt = (int)pt_tile.size() - 1;
         std::vector<int64_t> tp((size_t)nt + 1, 0);
@@ -95,7 +108,8 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         s.exact = exact;
         // hints index the caller's tiles: dropped once tiles had to be split
         s.tile_phase_hint = (attempt == 0 && d.tile_ptr && d.n_tiles > 0) ? d.tile_phase : nullptr;
-        s.slot_bits = (slot_bits == 12 && !exact && (L == 2 || L == 4)) ? 12 : 16;
+        s.slot_bits = (slot_bits == 12 && !exact && !dense_waves && (L == 2 || L == 4 || L == 8 || L == 16)) ? 12 : 16;
+        s.dense_waves = dense_waves;
         err = build_plan(s, out);
         if (err.rfind("slots-exceed-12-bit", 0) == 0) {  // a tile stages more than 4096 values: 16-bit slots
             s.slot_bits = 16;

@@ -17,8 +17,15 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
 
 // Plan A of a level: interior rows (bcflags == 0) in storage order, own range of
 // a tile == its points.  Tile boundaries come from desc.tile_ptr or tile_size.
-// slot_bits 12: packed 12-bit LDS slots where possible (L = 2 or 4, every tile <= 4096 slots), else 16.
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false, int slot_bits = 16);
+// slot_bits 12: packed 12-bit LDS slots where possible (L = 2 ... 16, every tile <= 4096 slots), else 16.
+// waves > 1: dense multi-wavefront layout (plan.hpp) with that many wavefronts per tile and
+// dense_lanes(L, average row length) lanes per row; falls back to the packed layout (waves 1) when the
+// rows are too long for it.
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false, int slot_bits = 16,
+                             int waves = 1);
+// lanes per row of a dense level plan: the caller's choice if it is 4, 8 or 16, else 16 for long rows
+// (3-D K = 50: 4 entries per lane), 8 for short ones
+int dense_lanes(int lanes_per_row, double avg_row_len);
 
 // Domain decomposition, exact (per-phase) ghost exchange: phase[i] = phase of the sweep in which
 // point i is relaxed by plan A (-1: never relaxed); ghost_mask[j] (ghost points, bcflags == 3) = bit

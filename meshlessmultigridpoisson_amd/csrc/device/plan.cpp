@@ -41,6 +41,7 @@ struct TileBuild {
     std::vector<uint32_t> ghead;
     std::vector<int32_t> nbr;  // coupled tiles (unsorted, may repeat)
     uint32_t n_own = 0, row0 = 0;
+    uint32_t n_levels = 0;
     long long nnz = 0;
     std::string err;
 };
@@ -162,6 +163,66 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             n_levels = std::max(n_levels, lv + 1);
         }
     }
+    tb.n_levels = (uint32_t)n_levels;
+    if (s.dense_waves > 0) {
+        // ---- dense multi-wavefront layout (plan.hpp) ----------------------------------------
+        // Rounds by list scheduling: in sequence order, a row goes into the first round after every
+        // coupled earlier row of the tile that still has room.  Coupled rows therefore keep their
+        // sequential order (strictly later round), rows of one round are mutually uncoupled.
+        const int NW = s.dense_waves, P = s.dense_plen;
+        const int cap = NW * G;
+        std::vector<int32_t> round_of(m, 0), fill;
+        for (int k = 0; k < m; ++k) {
+            int r = 0;
+            if (s.in_place)
+                for (int32_t j : lower[k]) r = std::max(r, round_of[j] + 1);
+            else
+                r = fill.empty() ? 0 : (int)fill.size() - 1;
+            while (r < (int)fill.size() && fill[r] >= cap) ++r;
+            if (r >= (int)fill.size()) fill.resize((size_t)r + 1, 0);
+            ++fill[r];
+            round_of[k] = r;
+            if ((int)((ent[k].size() + L - 1) / L) > P) { tb.err = "rows-too-long-for-dense"; return; }
+        }
+        const int n_rounds = (int)fill.size();
+        std::vector<std::vector<int32_t>> by_round(n_rounds);
+        for (int k = 0; k < m; ++k) by_round[round_of[k]].push_back(k);
+        const size_t GB = dense_group_bytes(L, P);
+        tb.blob.assign((size_t)n_rounds * NW * GB, 0);
+        uint8_t *B = tb.blob.data();
+        const size_t off_diag = (size_t)16 * G, off_val = off_diag + (size_t)8 * G, off_slot = off_val + (size_t)P * 512;
+        for (int r = 0; r < n_rounds; ++r) {
+            const auto &rows = by_round[r];
+            for (int w = 0; w < NW; ++w) {
+                uint8_t *gp = B + ((size_t)r * NW + w) * GB;
+                // everything empty first: no row, value 0, zero slot
+                for (int i = 0; i < G; ++i) {
+                    RowInfo ri{RowMeta{kNoRow, kNoSlot, 0}, 1.0};
+                    std::memcpy(gp + (size_t)16 * i, &ri, 16);
+                    const double one = 1.0;
+                    std::memcpy(gp + off_diag + (size_t)8 * i, &one, 8);
+                }
+                for (size_t i = 0; i < (size_t)64 * P; ++i) std::memcpy(gp + off_slot + 2 * i, &zero_slot, 2);
+                int active = 0;
+                for (size_t idx = (size_t)w, i = 0; idx < rows.size(); idx += NW, ++i) {  // rows w, w+NW, ... of the round
+                    const int k = rows[idx];
+                    RowInfo ri{meta[k], 1.0 / diag[k]};
+                    if (!s.extract_diag) ri.inv_diag = 1.0;
+                    std::memcpy(gp + (size_t)16 * i, &ri, 16);
+                    std::memcpy(gp + off_diag + (size_t)8 * i, &diag[k], 8);
+                    const auto &e = ent[k];
+                    for (size_t x = 0; x < e.size(); ++x) {
+                        const size_t q = x / L, lane = i * L + x % L;
+                        std::memcpy(gp + off_val + (q / 2) * 1024 + lane * 16 + (q % 2) * 8, &e[x].val, 8);
+                        std::memcpy(gp + off_slot + (lane * P + q) * 2, &e[x].slot, 2);
+                    }
+                    ++active;
+                }
+                tb.ghead.push_back((uint32_t)active | ((uint32_t)P << 8));
+            }
+        }
+        return;
+    }
     std::vector<std::vector<int32_t>> by_level(n_levels);
     for (int k = 0; k < m; ++k) by_level[level[k]].push_back(k);
 
@@ -228,15 +289,28 @@ std::string build_plan(const PlanSpec &s, Plan *out)
 {
     if (!out) return "null plan";
     const int L = s.L;
-    if (!(L == 1 || L == 2 || L == 4 || L == 8 || L == 16 || L == 32 || L == 64))
-        return "lanes_per_row must be a power of two <= 64";
+    if (!(L == 1 || L == 2 || L == 4 || L == 8 || L == 16))
+        return "lanes_per_row must be 1, 2, 4, 8 or 16";
     if (s.n_tiles < 1 || !s.tile_ptr || (!s.rows && s.n_rows > 0)) return "bad plan spec";
     if (s.tile_ptr[0] != 0 || s.tile_ptr[s.n_tiles] != s.n_rows) return "tile_ptr does not cover rows";
     const CsrView &A = s.A;
     const int n_in = A.cols;
+    PlanSpec sd = s;  // dense layout: entries per lane of every group fixed per plan (4 or 8)
+    if (s.dense_waves > 0) {
+        if (!(L == 4 || L == 8 || L == 16) || s.exact || s.slot_bits == 12) return "dense layout needs 4, 8 or 16 lanes per row and 16-bit slots";
+        if (s.dense_waves > 16) return "dense layout: at most 16 wavefronts per tile";
+        int maxlen = 0;
+        for (int64_t k = 0; k < s.n_rows; ++k) {
+            if (s.rows[k] < 0 || s.rows[k] >= A.rows) return "row id outside the matrix";
+            maxlen = std::max(maxlen, A.rowptr[s.rows[k] + 1] - A.rowptr[s.rows[k]]);
+        }
+        const int need = (maxlen + L - 1) / L;  // upper bound (diagonal / multiplier / explicit zeros still inside)
+        if (need > 8) return "rows-too-long-for-dense";
+        sd.dense_plen = need <= 4 ? 4 : 8;
+    }
 
     Ctx c;
-    c.s = &s;
+    c.s = &sd;
     if (s.in_place) {
         c.rowpos.assign(n_in, -1);
         c.tile_of.resize((size_t)s.n_rows);
@@ -285,6 +359,9 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     Plan &P = *out;
     P = Plan();
     P.L = L;
+    P.dense = s.dense_waves > 0;
+    P.waves = s.dense_waves > 0 ? s.dense_waves : 1;
+    P.dense_plen = sd.dense_plen;
     P.slot_bits = s.slot_bits == 12 ? 12 : 16;
     P.n_tiles = s.n_tiles;
     P.tiles.resize(s.n_tiles);
@@ -301,6 +378,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         d.n_groups = (uint32_t)tb[t].ghead.size();
         d.n_rows = (uint32_t)(s.tile_ptr[t + 1] - s.tile_ptr[t]);
         d.stream_len = (uint32_t)tb[t].blob.size();
+        d.n_levels = tb[t].n_levels;
         P.max_stream = std::max(P.max_stream, tb[t].blob.size());
         stream_sz += tb[t].blob.size();
         halo_sz += tb[t].halo.size();

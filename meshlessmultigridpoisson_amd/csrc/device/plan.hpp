@@ -24,6 +24,21 @@
 // `slot` is the tile-local LDS slot of the entry's column (16 bit: a stored
 // entry costs 10 B instead of CSR's 12 B).  Padding entries carry val = 0 and
 // point at the tile's zero slot.
+//
+// DENSE plans (Plan::dense; the latency-bound levels of a V-cycle).  A wavefront that is alone on its
+// SIMD issues one instruction every 4 cycles, and on levels too small to fill the device that -- the
+// instruction COUNT of a tile's dependency chain -- is what a sweep costs, not bytes.  Dense plans trade
+// bytes for instructions and let Plan::waves wavefronts (one workgroup) share a tile:
+//   * every group has the same shape: 64/L row slots, exactly `plen` (Plan::dense_plen: 4 or 8) entries
+//     per lane, lane stride 64 -- every address inside a group is a compile-time offset from the group
+//     base, group g of a tile starts at g * dense_group_bytes();
+//   * a ROUND is `waves` consecutive groups, one per wavefront, of mutually uncoupled rows; the rows of a
+//     tile are list-scheduled into rounds (a row goes into the first round after all coupled earlier
+//     rows that still has room), the wavefronts synchronise with one barrier per round;
+//   * layout of a group: RowInfo info[64/L] (16 B: RowMeta + 1/diag) | double diag[64/L] |
+//     double2 val[plen/2][64] (entries 2k, 2k+1 of a lane adjacent: one 16-byte load) |
+//     uint16 slot[plen][64] stored as plen/4 words of 8 B per lane.
+//     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -48,7 +63,7 @@ struct TileDesc {          // 48 bytes, read by the kernels with scalar loads
     uint32_t ghead_off;    // into Plan::ghead
     uint32_t n_rows;       // rows handled by the tile
     uint32_t stream_len;   // bytes of the tile's packed groups (multiple of 16)
-    uint32_t pad1;
+    uint32_t n_levels;     // dependency levels of the tile's rows (diagnostics)
 };
 static_assert(sizeof(TileDesc) == 48, "TileDesc layout");
 
@@ -60,6 +75,13 @@ struct RowMeta {
 };
 static_assert(sizeof(RowMeta) == 8, "RowMeta layout");
 
+struct RowInfo {           // dense plans: 16 bytes per row slot, one load
+    RowMeta meta;
+    double inv_diag;       // 1 / a_rr (SOR and the Neumann boundary solve multiply instead of dividing)
+};
+static_assert(sizeof(RowInfo) == 16, "RowInfo layout");
+
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;  // RowMeta::gid of an empty row slot (dense plans)
 constexpr uint16_t kNoSlot = 0xFFFF;
 constexpr int kMaxSlots = 7680;  // (slots + own rhs) * 8 B + group heads must fit 64 KiB of LDS
 
@@ -79,8 +101,18 @@ inline size_t group_bytes(int L, int g, int plen, int bits = 16)
     return (size_t)16 * g + align16((size_t)plen * W * 8) + align16(slot_words(bits, plen) * W * 8);
 }
 
+// byte size of one group of a dense plan (16-bit slots): info + diag + values + slots
+inline size_t dense_group_bytes(int L, int plen)
+{
+    const size_t G = (size_t)(64 / L);
+    return 16 * G + 8 * G + (size_t)plen * 64 * 8 + (size_t)plen * 64 * 2;
+}
+
 struct Plan {
     int L = 4;                         // lanes per row
+    bool dense = false;                // dense multi-wavefront layout (see the header comment)
+    int waves = 1;                     // wavefronts per tile (dense plans: groups per round)
+    int dense_plen = 0;                // entries per lane of every group (dense plans: 4 or 8)
     int slot_bits = 16;                // 16, or 12 when every tile has <= 4096 LDS slots (level plans, L = 2/4)
     int n_tiles = 0;
     std::vector<TileDesc> tiles;
@@ -104,7 +136,11 @@ struct Plan {
     long long n_nnz = 0;               // stored (non-padding) entries
     long long n_groups = 0;
     int n_phases() const { return (int)phase_ptr.size() - 1; }
-    size_t lds_bytes() const { return ((size_t)max_slots + (size_t)max_own) * 8 + (size_t)max_groups * 4; }
+    size_t lds_bytes() const
+    {
+        if (dense) return ((size_t)max_slots + (size_t)max_own) * 8 + 128;  // + cross-wavefront partial sums
+        return ((size_t)max_slots + (size_t)max_own) * 8 + (size_t)max_groups * 4;
+    }
     // the same plus room for one tile's whole packed stream (tile_kernel_lds)
     // (copied in 1-KiB LDS-DMA chunks: the last one may overhang by < 1 KiB)
     size_t lds_bytes_resident() const { return align16(lds_bytes()) + ((max_stream + 1023) & ~(size_t)1023) + 16; }
@@ -135,6 +171,10 @@ struct PlanSpec {
     // (mmg_level_set_exchange_mode); any value >= the dependency-derived phase keeps the schedule exact.
     const int32_t *tile_phase_hint = nullptr;
     int slot_bits = 16;         // 12: fails with "slots-exceed-12-bit" if a tile stages more than 4096 values
+    // dense multi-wavefront layout: waves > 0 selects it (L must be 4, 8 or 16; rows of at most 8 * L
+    // stored entries; 16-bit slots); fails with "rows-too-long-for-dense" otherwise
+    int dense_waves = 0;
+    int dense_plen = 0;         // set by build_plan
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).

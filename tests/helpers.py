@@ -80,6 +80,35 @@ def device_hierarchy(case, frac_step=None, **kw):
     return _capi.Hierarchy(levels, R, P, frac_step=fs)
 
 
+def oracle_of_multigrid(mg):
+    """The hierarchy a host `Multigrid` handle built, as CPU-oracle objects (checker only)."""
+    from oracle import oracle_c as oc
+    nl = mg.nlevels
+    levels = []
+    for l in range(nl):
+        la = mg.grid(l).level_arrays(mg.omega, mg.iters)
+        levels.append(oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"],
+                               la["neumann"], la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"],
+                               la["bvals"]))
+    R, P = [None] * nl, [None] * nl
+    for l in range(nl):
+        t = mg.transfer("R", l)
+        if t:
+            R[l] = oc.Transfer.from_dict(t)
+        t = mg.transfer("P", l)
+        if t:
+            P[l] = oc.Transfer.from_dict(t)
+    return oc.Multigrid(levels, R, P, frac_step=bool(getattr(mg, "frac_step", False)))
+
+
+def oracle_of_fracstep(g):
+    """Oracle objects over the operators a host `FracStepGrid` built (checker only)."""
+    from oracle import oracle_c as oc
+    nx, ny = g.normals()
+    _bt, _bp, bpts, _bv = g.boundaries()
+    return oc.FracStep(g.sizes()["n"], g.op(0), g.op(1), g.op(2), nx, ny, bpts)
+
+
 # ---- CPU interpreter of the packed plan (tests/support/plan_emulate.cpp) ------------
 _emu = None
 
@@ -102,6 +131,8 @@ def emu_lib():
         L.emu_level_sor_one_phase.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int]
         L.emu_level_point_phases.argtypes = [C.c_void_p, C.c_void_p, _ip, C.POINTER(C.c_ulonglong)]
         L.emu_level_owned_sum.restype = C.c_double
+        L.emu_level_slot_bits.argtypes = [C.c_void_p]
+        L.emu_level_waves.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.restype = C.c_longlong
         L.emu_level_nnz.argtypes = [C.c_void_p]
@@ -112,11 +143,11 @@ def emu_lib():
 
 
 class EmuLevel:
-    def __init__(self, la, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None):
+    def __init__(self, la, tile_ptr=None, tile_size=0, lanes_per_row=0, tile_phase=None, waves_per_tile=0):
         from meshlessmultigridpoisson_amd import _capi
         d, self._keep = _capi.make_desc(la["n"], la["rowptr"], la["col"], la["val"], la["bcflags"], la["neumann"],
                                         la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"],
-                                        tile_ptr, tile_size, lanes_per_row, tile_phase)
+                                        tile_ptr, tile_size, lanes_per_row, tile_phase, waves_per_tile)
         self.L = emu_lib()
         self._desc = d
         self._neumann = bool(la["neumann"])

@@ -32,6 +32,75 @@ struct Emu {
 
 thread_local std::string g_err;
 
+// Dense multi-wavefront plans (plan.hpp): `waves` groups form a round and run concurrently on the
+// device, so ALL rows of a round read LDS before any of them writes.
+void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<double> &xs, double *out, const double *b,
+                    double omega, double lam, double *abs_acc)
+{
+    const int L = P.L, G = 64 / L, NW = P.waves, PL = P.dense_plen;
+    const size_t GB = dense_group_bytes(L, PL);
+    const size_t off_diag = (size_t)16 * G, off_val = off_diag + (size_t)8 * G, off_slot = off_val + (size_t)PL * 512;
+    const uint8_t *base = P.stream.data() + td.stream_off;
+    struct Upd { RowMeta m; double acc, d, invd; };
+    for (uint32_t r0 = 0; r0 < td.n_groups; r0 += (uint32_t)NW) {
+        std::vector<Upd> upd;
+        for (int w = 0; w < NW; ++w) {
+            const uint8_t *gp = base + (size_t)(r0 + w) * GB;
+            const uint32_t h = P.ghead[td.ghead_off + r0 + w];
+            int seen = 0;
+            for (int i = 0; i < G; ++i) {
+                RowInfo ri;
+                std::memcpy(&ri, gp + (size_t)16 * i, 16);
+                if (ri.meta.gid == kNoRow) continue;
+                ++seen;
+                double d;
+                std::memcpy(&d, gp + off_diag + (size_t)8 * i, 8);
+                double lane_acc[64] = {0};
+                for (int sub = 0; sub < L; ++sub) {
+                    const size_t lane = (size_t)i * L + sub;
+                    double a0 = 0.0, a1 = 0.0;  // the kernels keep two accumulators per lane (even / odd entries)
+                    for (int q = 0; q < PL; ++q) {
+                        double v;
+                        uint16_t sl;
+                        std::memcpy(&v, gp + off_val + (size_t)(q / 2) * 1024 + lane * 16 + (size_t)(q % 2) * 8, 8);
+                        std::memcpy(&sl, gp + off_slot + (lane * PL + q) * 2, 2);
+                        if (q & 1) a1 = std::fma(v, xs[sl], a1);
+                        else a0 = std::fma(v, xs[sl], a0);
+                    }
+                    lane_acc[sub] = a0 + a1;
+                }
+                for (int m = 1; m < L; m <<= 1)
+                    for (int sub = 0; sub < L; sub += 2 * m) lane_acc[sub] += lane_acc[sub + m];
+                upd.push_back(Upd{ri.meta, lane_acc[0], d, ri.inv_diag});
+            }
+            if (seen != (int)(h & 0xffu)) g_err = "dense group head disagrees with its row slots";
+        }
+        for (const Upd &u : upd) {
+            const RowMeta m = u.m;
+            if (mode == M_SOR) {
+                double xi = b[m.gid] - u.acc;
+                if (m.flags & 1) xi -= lam;
+                xi *= omega * u.invd;
+                xi += (1.0 - omega) * xs[m.self];
+                xs[m.self] = xi;
+            } else if (mode == M_BOUND) {
+                const double xi = (b[m.gid] - u.acc) * u.invd;
+                out[m.gid] = xi;
+                if (m.self != kNoSlot) xs[m.self] = xi;
+            } else if (mode == M_RESID) {
+                double rr = b[m.gid] - (u.acc + u.d * xs[m.self]);
+                if (m.flags & 1) rr -= lam;
+                out[m.gid] = rr;
+                if (abs_acc) *abs_acc += std::fabs(rr);
+            } else if (mode == M_SET) {
+                out[m.gid] = u.acc;
+            } else {
+                out[m.gid] += u.acc;
+            }
+        }
+    }
+}
+
 void run_tile(const Plan &P, int tile, int mode, const double *in, double *out, const double *b, double omega,
               double lam, double *abs_acc)
 {
@@ -42,6 +111,12 @@ void run_tile(const Plan &P, int tile, int mode, const double *in, double *out, 
     for (uint32_t i = 0; i < td.n_own; ++i) xs[i] = in[td.row0 + i];
     for (uint32_t i = 0; i < td.n_halo; ++i) xs[td.n_own + i] = in[P.halo[td.halo_off + i]];
     xs[n_slots - 1] = 0.0;
+    if (P.dense) {
+        run_tile_dense(P, td, mode, xs, out, b, omega, lam, abs_acc);
+        if (mode == M_SOR)
+            for (uint32_t i = 0; i < td.n_own; ++i) out[td.row0 + i] = xs[i];
+        return;
+    }
     const uint8_t *p = P.stream.data() + td.stream_off;
     for (uint32_t g = 0; g < td.n_groups; ++g) {
         const uint32_t h = P.ghead[td.ghead_off + g];
@@ -146,7 +221,7 @@ void *emu_level_create(const mmg_level_desc *d)
     const int L = d->lanes_per_row > 0 ? d->lanes_per_row : 4;
     std::string err = check_multiplier(*d);
     if (err.empty()) err = build_boundary_lists(*d, &e->bl);
-    if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits);
+    if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits, d->waves_per_tile > 1 ? d->waves_per_tile : 1);
     if (err.empty() && !e->bl.neu_rows.empty()) {
         CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
         err = build_gather_plan_host(A, e->bl.neu_rows, L, 64, true, true, true, -1, &e->B);
@@ -170,6 +245,7 @@ void emu_level_info(void *h, int *out6)
 }
 
 int emu_level_slot_bits(void *h) { return static_cast<Emu *>(h)->A.slot_bits; }
+int emu_level_waves(void *h) { return static_cast<Emu *>(h)->A.dense ? static_cast<Emu *>(h)->A.waves : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
 

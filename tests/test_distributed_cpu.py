@@ -373,7 +373,7 @@ def test_distributed_vcycle_matches_hybrid_oracle(neumann):
     nparts = 2
     clouds = [host.square_cloud(n, seed=300 + i) for i, n in enumerate([13, 25, 41])]
     mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
-    om = mg.oracle()
+    om = H.oracle_of_multigrid(mg)
     parts = [mg.level_part(l, nparts) for l in range(mg.nlevels)]
     subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
     ranks = [_Rank(host, s, r) for r, s in enumerate(subs)]
@@ -431,7 +431,7 @@ def test_distributed_vcycle_exact_exchange_matches_plain_oracle(neumann):
     nparts = 2
     clouds = [host.square_cloud(n, seed=300 + i) for i, n in enumerate([13, 25, 41])]
     mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
-    om = mg.oracle()
+    om = H.oracle_of_multigrid(mg)
     subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
     ranks = [_Rank(host, s, r, hints=True) for r, s in enumerate(subs)]
     for l in range(mg.nlevels):

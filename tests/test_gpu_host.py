@@ -27,7 +27,7 @@ def test_run_mg_sim_sequence_matches_oracle(host, ordering, neumann):
     polys = [3, 3, 3] if neumann else [3, 3, 4]
     mg = host.Multigrid(clouds, polys, neumann=neumann,
                         ordering=host.ORDER_RCM if ordering == "rcm" else host.ORDER_MC, tile_points=128)
-    om = mg.oracle()
+    om = H.oracle_of_multigrid(mg)
     for k in range(12):
         ro = om.vcycle()
         rd = mg.vcycle()
@@ -127,7 +127,7 @@ def test_baseline_config1_1e4_points_3_levels(host):
             assert np.array_equal(back, pts)  # %.17g round-trips exactly, boundary coordinates stay 0/1
             clouds.append(back)
     mg = host.Multigrid(clouds, [3, 3, 4], neumann=False, ordering=host.ORDER_MC, tile_points=0)
-    om = mg.oracle()
+    om = H.oracle_of_multigrid(mg)
     for k in range(10):
         ro, rd = om.vcycle(), mg.vcycle()
         assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
@@ -145,7 +145,7 @@ def test_fractional_step_grid_ops_match_oracle(host):
     following one time step of FractionalStepSim.cpp:130-147."""
     pts = host.square_cloud(29, seed=8)
     g = host.FracStepGrid.create(pts, polydeg=3, dt=2e-4, mu=0.025, rho=1.0, ordering=host.ORDER_MC, tile_points=128)
-    o = g.oracle()
+    o = H.oracle_of_fracstep(g)
     n = g.sizes()["n"]
     g.prescribe_soln()
     rng = np.random.default_rng(0)
@@ -185,7 +185,7 @@ def test_cpp_setup_exchange_single_rank_hierarchy(host, neumann):
     from meshlessmultigridpoisson_amd import _capi
     clouds = [host.square_cloud(n, seed=77 + i) for i, n in enumerate([13, 25, 41])]
     mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
-    om = mg.oracle()
+    om = H.oracle_of_multigrid(mg)
     sub = mg.extract_subdomain(1, 0)
     for l in range(sub.nlevels):
         nbr, sp, si, rp = sub.grid(l).exchange_lists()

@@ -63,6 +63,66 @@ def test_sweeps_residual_match_oracle(name, tile, L, sweep_mode):
     assert abs(d.residual_ratio() - float(case["fine_ratio_after_sor"])) <= 1e-10 * float(case["fine_ratio_after_sor"])
 
 
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 8), (48, 4, 4)])
+@pytest.mark.parametrize("mode", [0, 1, 4], ids=["per-phase", "auto", "single-launch"])
+def test_dense_multiwave_kernels_match_oracle(name, tile, L, waves, mode):
+    """Dense plans (mmg_level_desc.waves_per_tile > 1): workgroups of `waves` wavefronts per tile, one barrier
+    per round of mutually uncoupled rows (kernels_mw.hip) -- per-phase launches (tile_kernel_mw), the resident
+    whole-sweep kernel ("auto" on these small levels: sweep_resident_mw) and the dependency-driven single launch
+    (sweep_persistent_mw).  Same coupled-row order => the oracle's iterates to 1e-12; the three drivers agree bitwise."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    la = H.level_arrays(case, case["nlevels"] - 1)
+    o = H.oracle_level(la)
+    _capi.set_option("persistent_sweep", mode)
+    try:
+        d = H.device_level(la, tile_size=tile, lanes_per_row=L, waves_per_tile=waves)
+        dense = d.info()["waves_per_tile"] == waves      # rows too long for the dense shape: packed fallback
+        assert dense or L == 4      # 4 lanes: K = 37 rows and the Neumann rows with elimination fill exceed 8 entries per lane
+        o.boundary_op(0)
+        d.boundary_op(0)
+        o.sor_sweeps(1)
+        d.sweeps(1)
+        assert H.rel_err(d.get_x(), o.x) < 1e-12
+        o.sor_sweeps(o.iters - 1)
+        d.sweeps(o.iters - 1)
+        assert H.rel_err(d.get_x(), o.x) < 1e-12
+        r, ro = d.residual(), o.residual()
+        assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(o.b).max())
+        assert abs(d.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio()
+        x_mode = d.get_x()
+        _capi.set_option("persistent_sweep", 0)
+        ref = H.device_level(la, tile_size=tile, lanes_per_row=L, waves_per_tile=waves)
+        ref.boundary_op(0)
+        ref.sweeps(1)
+        ref.sweeps(o.iters - 1)
+        assert np.array_equal(ref.get_x(), x_mode)
+    finally:
+        _capi.set_option("persistent_sweep", 1)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_vcycle_residual_history_dense_levels(name):
+    """Whole V-cycles with every level in the dense multi-wavefront layout (mmg_set_option("waves_per_tile", 4))."""
+    _need_gpu()
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case(name)
+    om = H.oracle_multigrid(case)
+    _capi.set_option("waves_per_tile", 4)
+    try:
+        dh = H.device_hierarchy(case)
+        assert all(l.info()["waves_per_tile"] == 4 for l in dh.levels)
+        for k in range(len(case["resid_history"])):
+            ro, rd = om.vcycle(), dh.vcycle()
+            assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+        # (the coarse levels hold corrections of the size of the converged residual: rounding noise by now)
+        assert H.rel_err(dh.levels[-1].get_x(), om.levels[-1].x) < 1e-9
+    finally:
+        _capi.set_option("waves_per_tile", 0)
+
+
 @pytest.mark.parametrize("name", ["neumann_2level", "neumann_3level"])
 def test_bound_eval_and_rhs_ops(name):
     _need_gpu()

@@ -12,7 +12,7 @@ CASES = ["dirichlet_3level", "neumann_2level", "neumann_3level", "dirichlet_2lev
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("tile,L", [(64, 4), (256, 2), (100, 16), (512, 1), (37, 64)])
+@pytest.mark.parametrize("tile,L", [(64, 4), (256, 2), (100, 16), (512, 1), (37, 8)])
 def test_sweeps_match_oracle(name, tile, L):
     case = H.load_case(name)
     la = H.level_arrays(case, case["nlevels"] - 1)
@@ -27,6 +27,48 @@ def test_sweeps_match_oracle(name, tile, L):
     ro = o.residual()
     assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(o.b).max())
     assert abs(nrm - np.abs(ro).sum()) <= 1e-10 * np.abs(ro).sum() + 1e-12
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 8), (48, 16, 2)])
+def test_dense_multiwave_layout_matches_oracle(name, tile, L, waves):
+    """Dense plans (plan.hpp): fixed-shape groups, rows list-scheduled into rounds of `waves` groups.  The
+    interpreter lets ALL rows of a round read before any of them writes (the wavefronts of a workgroup run a
+    round concurrently) -- sweeps and residuals must still be the oracle's sequential ones."""
+    import ctypes
+    case = H.load_case(name)
+    la = H.level_arrays(case, case["nlevels"] - 1)
+    o = H.oracle_level(la)
+    e = H.EmuLevel(la, tile_size=tile, lanes_per_row=L, waves_per_tile=waves)
+    lib = H.emu_lib()
+    lib.emu_level_waves.argtypes = [ctypes.c_void_p]
+    assert lib.emu_level_waves(e.h) == waves
+    assert lib.emu_level_slot_bits(e.h) == 16
+    o.boundary_op(0)
+    e.x[:] = o.x
+    o.sor_sweeps(3)
+    e.sweeps(3)
+    assert H.rel_err(e.x, o.x) < 1e-12
+    r, nrm = e.residual()
+    ro = o.residual()
+    assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(o.b).max())
+    assert abs(nrm - np.abs(ro).sum()) <= 1e-10 * np.abs(ro).sum() + 1e-12
+    assert lib.emu_last_error() in (b"", None) or b"dense group head" not in lib.emu_last_error()
+
+
+def test_dense_layout_falls_back_for_long_rows():
+    """Rows of more than 8 entries per lane do not fit the dense group shape: the level keeps the packed stream."""
+    import ctypes
+    case = H.load_case("dirichlet_3level")
+    la = H.level_arrays(case, 2)      # polyDeg 4: K = 37 -> 36 off-diagonal entries, 9 per lane at L = 4
+    e = H.EmuLevel(la, tile_size=64, lanes_per_row=4, waves_per_tile=4)
+    lib = H.emu_lib()
+    lib.emu_level_waves.argtypes = [ctypes.c_void_p]
+    assert lib.emu_level_waves(e.h) == 0
+    o = H.oracle_level(la)
+    o.sor_sweeps(2)
+    e.sweeps(2)
+    assert H.rel_err(e.x, o.x) < 1e-12
 
 
 @pytest.mark.parametrize("name", ["neumann_2level", "neumann_3level"])
@@ -87,7 +129,7 @@ def test_explicit_zeros_are_dropped_but_multiplier_kept():
 
 
 def test_twelve_bit_slot_stream_and_sixteen_bit_option():
-    """Level plans with L = 2 / 4 and <= 4096 LDS slots per tile pack the tile-local column indices in 12 bits
+    """Level plans with L = 2 ... 16 and <= 4096 LDS slots per tile pack the tile-local column indices in 12 bits
     (plan.hpp: slot_words; the default); mmg_set_option("slot_bits", 16) keeps 16-bit slots.  Same rows, same
     entries, fewer stream bytes, same arithmetic."""
     import ctypes
@@ -99,8 +141,10 @@ def test_twelve_bit_slot_stream_and_sixteen_bit_option():
     assert L.emu_level_slot_bits(e12.h) == 12
     e12n = H.EmuLevel(H.level_arrays(H.load_case("neumann_3level"), 2), tile_size=48, lanes_per_row=4)
     assert L.emu_level_slot_bits(e12n.h) == 12
-    e8 = H.EmuLevel(la, tile_size=64, lanes_per_row=8)       # other lane counts keep 16-bit slots
-    assert L.emu_level_slot_bits(e8.h) == 16
+    e8 = H.EmuLevel(la, tile_size=64, lanes_per_row=8)
+    assert L.emu_level_slot_bits(e8.h) == 12
+    e1 = H.EmuLevel(la, tile_size=64, lanes_per_row=1)       # one lane per row keeps 16-bit slots
+    assert L.emu_level_slot_bits(e1.h) == 16
     L.emu_set_slot_bits(16)
     try:
         e16 = H.EmuLevel(la, tile_size=64, lanes_per_row=2)
