@@ -13,8 +13,15 @@ by mmg_rbf_weights during the untimed setup).  --operator graph selects the synt
 kNN-graph Laplacian on the same sparsity instead (same bytes per row).  All inputs are
 resident in HBM before the timed region.
 
-N>1 (one process per GPU, torch.distributed/RCCL): weak scaling, every rank owns one
-such sub-domain of an N-times larger cloud; see DESIGN.md "Multi-GPU".
+N>1 (one process per GPU, torch.distributed/RCCL): `--scaling weak` (default): every rank owns
+one such 216^3 sub-domain of an N-times larger cloud.  `--scaling strong --total-nside 342`: the N
+ranks share ONE 342^3 = 4.0e7-point cloud (BASELINE configs[3] at N = 8), cut into x-slabs.
+Launch: `python bench.py --gpus N ...` starts torch.distributed.run itself (one rank per GPU,
+127.0.0.1 rendezvous) when it is not already running under it; see DESIGN.md "Multi-GPU".
+
+At N=1 the line also carries two `vcycle` objects: whole Multigrid::vCycle timings (multigrid.cpp:62-110)
+on BASELINE configs[1] (2-D 1e6 points, 5 levels) and on the 216^3 4-level hierarchy whose finest grid the
+sweep figures are measured on, each with its algorithmic bytes per cycle against 8 TB/s.
 
 Prints ONE JSON line on rank 0.
 """
@@ -66,6 +73,11 @@ def parse():
     ap.add_argument("--exchange", choices=("sweep", "phase"), default="sweep",
                     help="N>1: ghost refresh once per sweep (block-hybrid Gauss-Seidel, default) or before every phase "
                          "(exact: the sequential reference sweep on the global system)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N>1: weak = --nside^dim points per rank; strong = one --total-nside^dim cloud shared by all ranks")
+    ap.add_argument("--total-nside", type=int, default=342, help="--scaling strong: points per axis of the whole cloud")
+    ap.add_argument("--no-vcycle", action="store_true", help="skip the two whole-V-cycle legs (N=1)")
+    ap.add_argument("--vcycle-cycles", type=int, default=10)
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
     return ap.parse_args()
@@ -92,12 +104,112 @@ def cpu_baseline(grid, stencil, budget_s):
     lv.sor_sweeps(n)
     dt = time.perf_counter() - t0
     return {"value": interior * n / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
-            "sample": f"{n} sweeps over the same {la['n']}-point level (K={stencil}), oracle/mmg_oracle.c "
-                      f"{'-O3 -march=native' if fast else '-O2'}, 1 thread"}
+            "sample": f"{n} sweeps over the same {la['n']}-point level (K={stencil}) by the CPU restatement "
+                      f"oracle/mmg_oracle.c (the reference itself needs Eigen, absent here: kind 'port'), "
+                      f"{'-O3 -march=native -ffp-contract=off' if fast else '-O2'}, 1 thread -- the reference is single-threaded",
+            "host": host_description()}
+
+
+def host_description():
+    """nproc, CPU model, compiler: what BASELINE.md section 2 asks to be stated next to the CPU figure."""
+    import subprocess
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:  # noqa: BLE001
+        cc = "gcc (version unknown)"
+    return {"nproc": os.cpu_count(), "cpu_model": model, "compiler": cc}
+
+
+def algorithmic_bytes_per_vcycle(levels, k_interp, iters):
+    """SURVEY 8d, summed over the levels of one V-cycle (multigrid.cpp:62-110).
+    levels: coarse -> fine, dicts with n (points), interior (relaxed rows), K (stencil).
+    Per level: 2 * iters sweeps (the coarsest level is smoothed twice as well, :94-95) at 12K + 28 B per
+    relaxed row; residual passes at 12K + 24 B per point: 2 on the finest level (:66 and :81), 1 on the
+    intermediate ones (:81), none on the coarsest; restriction 12 K_I + 16 B per coarse row, prolongation
+    12 K_I + 24 B per fine row, per level pair."""
+    total = 0.0
+    nl = len(levels)
+    for l, lv in enumerate(levels):
+        total += 2 * iters * lv["interior"] * (12 * lv["K"] + 28)
+        nres = 2 if l == nl - 1 else (1 if l > 0 else 0)
+        total += nres * lv["n"] * (12 * lv["K"] + 24)
+        if l > 0:
+            total += levels[l - 1]["n"] * (12 * k_interp + 16) + lv["n"] * (12 * k_interp + 24)
+    return total
+
+
+def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
+    """Time `cycles` device-resident V-cycles of a host Multigrid (after 3 warm-up cycles)."""
+    from meshlessmultigridpoisson_amd import _capi, _host
+    mg.vcycles(3)
+    res, ms = mg.vcycles(cycles)
+    levels = []
+    for l in range(mg.nlevels):
+        g = mg.grid(l)
+        sz = g.sizes()
+        info = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"]).info()
+        levels.append({"n": sz["n"], "interior": info["sor_rows"], "K": _host.stencil_size(polys[l], dim),
+                       "tiles": info["n_tiles"], "lanes_per_row": info["lanes_per_row"],
+                       "waves_per_tile": info["waves_per_tile"]})
+    k_i = _host.stencil_size(polys[-1], dim)
+    alg = algorithmic_bytes_per_vcycle(levels, k_i, iters)
+    per = ms / cycles
+    out = {"workload": what, "levels": sides, "polydeg": polys, "cycles": cycles, "ms_per_vcycle": per,
+           "algorithmic_bytes_per_vcycle": alg, "achieved": alg / (per * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "fine_Mpoints_per_s": sides[-1] ** dim / (per * 1e-3) / 1e6,
+           "layout": [{k: lv[k] for k in ("n", "tiles", "lanes_per_row", "waves_per_tile")} for lv in levels],
+           "residual_history_first_cycles": [float(r) for r in mg.residuals[:4]],
+           "tolerance_vs_cpu_oracle": "1e-10 relative for rho >= 2e-3, 2e-13 absolute below (evaluation noise of rho); "
+                                      "exact-arithmetic mode bitwise (tests/test_gpu_parity.py, tests/test_gpu_configs.py)",
+           "sweep_fallbacks": _capi.get_counter("sweep_fallbacks")}
+    if oracle_cycles > 0:
+        from tests import helpers as H     # cpu_baseline leg: the oracle is the checker / the CPU reference figure
+        om = H.oracle_of_multigrid(mg)     # state after the GPU cycles: the continuation is compared
+        t0 = time.perf_counter()
+        ro = [om.vcycle() for _ in range(oracle_cycles)]
+        out["cpu_oracle_ms_per_vcycle"] = (time.perf_counter() - t0) / oracle_cycles * 1e3
+        rd = [mg.vcycle() for _ in range(oracle_cycles)]
+        out["max_rel_residual_diff_vs_cpu_oracle"] = float(max(abs(x - y) / y for x, y in zip(rd, ro)))
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start it (one rank per GPU, 127.0.0.1
+    rendezvous) as a CHILD process -- nothing in this process has touched the GPU yet -- and relay its one
+    JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is not None:
+        print(line, flush=True)
+    elif r.stdout:
+        sys.stderr.write(r.stdout)
+    sys.exit(r.returncode if r.returncode else (0 if line else 1))
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(a)   # does not return
     # stdout carries exactly ONE JSON line.  RCCL prints a version banner on stdout when a communicator is
     # created (torch's and the library's own): everything but the final line goes to stderr.
     sys.stdout.flush()
@@ -106,6 +218,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1 or (a.force_dd and "RANK" in os.environ):
         import torch
@@ -131,21 +245,46 @@ def main():
         cus, lds = _capi.device_props()
     except Exception:
         cus, lds = 0, 0
-    if a.tile <= 0:
-        a.tile = _capi.auto_tile_points(a.nside ** a.dim, a.dim, stencil, a.lanes, cus, lds)
     dd = world > 1 or a.force_dd
+    strong = dd and a.scaling == "strong"
+    if strong:
+        lo_x, hi_x = _host.slab_bounds(rank, world, a.total_nside)
+        pts_per_rank = (hi_x - lo_x) * a.total_nside ** (a.dim - 1)
+    else:
+        pts_per_rank = a.nside ** a.dim
+    if a.tile <= 0:
+        a.tile = _capi.auto_tile_points(pts_per_rank, a.dim, stencil, a.lanes, cus, lds)
     kind = _host.KIND_DIRICHLET if a.operator == "rbf" else _host.KIND_GRAPH
     if a.operator == "rbf":
         _host.set_option("device_setup", 1)   # the 70 x 70 saddle systems of 1e7 stencils: seconds on the GPU
+    mg3 = None
+    vcycles = []
+    want_vcycle = not dd and not a.no_vcycle and a.dim == 3 and a.operator == "rbf"
     if not dd:
-        pts = _host.box_cloud(a.nside, a.dim, seed=12345)
-        grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=kind, ordering=_host.ORDER_MC,
-                                        tile_points=a.tile, lanes_per_row=a.lanes)
+        if want_vcycle:
+            # the 4-level hierarchy whose finest grid is the bench level (BASELINE configs[2] + its V-cycle)
+            sides3 = [max(9, a.nside // (2 ** (3 - l))) for l in range(4)]
+            polys3 = [a.polydeg] * 4
+            clouds = [_host.box_cloud(n, 3, seed=12345 + (3 - i)) for i, n in enumerate(sides3)]
+            clouds[-1] = _host.box_cloud(a.nside, a.dim, seed=12345)
+            mg3 = _host.Multigrid(clouds, polys3, dim=3, neumann=False, ordering=_host.ORDER_MC, tile_points=0,
+                                  lanes_per_row=a.lanes)
+            grid = mg3.grid(3)
+            a.tile = None
+        else:
+            pts = _host.box_cloud(a.nside, a.dim, seed=12345)
+            grid = _host.Grid.create_square(pts, a.polydeg, dim=a.dim, kind=kind, ordering=_host.ORDER_MC,
+                                            tile_points=a.tile, lanes_per_row=a.lanes)
         n_owned = grid.sizes()["n"]
     else:
-        # domain decomposition: rank r owns x-layers [r*nside, (r+1)*nside) of a (world*nside) x nside^(dim-1)
-        # lattice and builds ONLY its own rows; ghost ids are agreed on with one all_gather at setup
-        pts, flags, gid, owner = _host.slab_cloud(rank, world, a.nside, dim=a.dim, margin=5)
+        # domain decomposition into x-slabs: every rank builds ONLY its own rows from its lattice layers plus a
+        # margin; ghost ids are agreed on with one all_gather at setup.  weak: rank r owns layers
+        # [r*nside, (r+1)*nside) of a (world*nside) x nside^(dim-1) lattice; strong: an equal share of the
+        # layers of ONE total_nside^dim lattice on the unit cube
+        if strong:
+            pts, flags, gid, owner = _host.slab_cloud(rank, world, a.total_nside, dim=a.dim, margin=5, total=True)
+        else:
+            pts, flags, gid, owner = _host.slab_cloud(rank, world, a.nside, dim=a.dim, margin=5)
         grid = _host.Grid.create_local(pts, flags, gid, owner, a.dim, stencil, tile_points=a.tile, lanes_per_row=a.lanes,
                                        kind=kind, polydeg=a.polydeg)
         n_owned, lgid, gown = grid.local_map()
@@ -163,10 +302,6 @@ def main():
             dist.broadcast_object_list(ids, src=0)
         _capi.comm_init(rank, world, ids[0])
     sz = grid.sizes()
-    rng = np.random.default_rng(7 + rank)
-    rhs = rng.standard_normal(sz["a_size"])
-    rhs[n_owned:] = 0.0
-    grid.set_source(rhs)
     lv = _capi.Level.borrow(grid.device_level(), sz["n"], sz["a_size"])
     if dd:
         lv.set_exchange(n_owned, nbr, sp, si, rp)
@@ -175,6 +310,22 @@ def main():
     info = lv.info()
     t_setup = time.perf_counter() - t_setup
     interior = info["sor_rows"]
+
+    # ---- whole V-cycles (N = 1): 216^3 4 levels on the hierarchy just built, then BASELINE configs[1] ----
+    if mg3 is not None:
+        try:
+            vcycles.append(vcycle_leg(mg3, f"3-D {a.nside}^3 = {a.nside ** 3} points, 4 levels {sides3}, RBF-FD degree "
+                                           f"{a.polydeg} (K={stencil}) on every level, Dirichlet, omega 1.4, V(5,5) "
+                                           f"(the hierarchy above BASELINE configs[2]'s grid)", 3, sides3, polys3,
+                                      a.vcycle_cycles, 5, oracle_cycles=0 if a.no_cpu else 1))
+        except Exception as e:  # noqa: BLE001 -- the sweep figures below do not depend on this leg
+            vcycles.append({"workload": "3-D 4-level V-cycle", "error": str(e)})
+    rng = np.random.default_rng(7 + rank)
+    rhs = rng.standard_normal(sz["a_size"])
+    rhs[n_owned:] = 0.0
+    grid.set_source(rhs)
+    grid.set_values(np.zeros(sz["a_size"]))
+    grid.device_level()   # host writes through values_ / source_ reach the device (Grid::sync_to_device)
 
     def barrier():
         if dist is not None:
@@ -247,7 +398,28 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    if not dd and not a.no_vcycle and a.operator == "rbf":
+        try:
+            sides2 = [62, 125, 250, 500, 1000]
+            polys2 = [3, 3, 3, 3, 4]
+            t2 = time.perf_counter()
+            mg2 = _host.Multigrid([_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides2)], polys2, dim=2,
+                                  neumann=False, ordering=_host.ORDER_MC, tile_points=0)
+            leg = vcycle_leg(mg2, "BASELINE configs[1]: 2-D 1000^2 = 1e6 points, 5 levels, RBF-FD degree 4 (K=37) on the "
+                                  "finest level, 3 (K=25) below, Dirichlet, omega 1.4, V(5,5)", 2, sides2, polys2,
+                             2 * a.vcycle_cycles, 5, oracle_cycles=0 if a.no_cpu else 3)
+            leg["setup_seconds"] = round(time.perf_counter() - t2, 1)
+            vcycles.insert(0, leg)
+            del mg2
+        except Exception as e:  # noqa: BLE001
+            vcycles.insert(0, {"workload": "BASELINE configs[1]", "error": str(e)})
+
     if rank == 0:
+        if strong:
+            wl = (f"{a.dim}-D {a.total_nside}^{a.dim} = {a.total_nside ** a.dim} points in ONE cloud shared by {world} "
+                  f"GPUs (x-slabs; BASELINE configs[3] at 8 GPUs)")
+        else:
+            wl = f"{a.dim}-D {a.nside}^{a.dim} = {n_owned} points per GPU"
         out = {
             "metric": "fine-grid smoother Mpoints/s + achieved HBM GB/s vs roofline, 1/2/4/8 GPU",
             "value": total_points * a.steps / dt / 1e6,
@@ -257,17 +429,18 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{a.dim}-D {a.nside}^{a.dim} = {n_owned} points per GPU, K={stencil} "
+                "workload": wl + f", K={stencil} "
                             f"kNN stencils ({'RBF-FD Laplacian, PHS r^3 + degree-' + str(a.polydeg) + ' polynomials' if a.operator == 'rbf' else 'graph-Laplacian values on the RBF-FD sparsity'}), Dirichlet, "
-                            f"one SOR sweep per step (BASELINE configs[2])",
+                            f"one SOR sweep per step" + ("" if strong else " (BASELINE configs[2])"),
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
-                "ordering": "mc_order_points", "tile_points": a.tile, "tiles": info["n_tiles"],
+                "ordering": "mc_order_points", "tile_points": int(round(n_owned / max(1, info["n_tiles"]))), "tiles": info["n_tiles"],
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
+                "waves_per_tile": info["waves_per_tile"],
                 "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches <= sweeps_timed), "sweeps_executed": a.warmup + a.steps + sweeps_timed + 2 * a.verify,
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if not dd else
@@ -276,6 +449,7 @@ def main():
                                   "before every phase (exact sequential Gauss-Seidel on the global system)")
                                + f", {sz['n'] - n_owned} ghost values per rank",
                 "setup_seconds": round(t_setup, 1),
+                "sweep_fallbacks": _capi.get_counter("sweep_fallbacks"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -288,6 +462,8 @@ def main():
             },
         }
         out["spmv"] = spmv
+        if vcycles:
+            out["vcycle"] = vcycles
         if verify is not None:
             out["config"]["persistent_vs_phase_launches"] = verify
         if not a.no_cpu and world == 1:

@@ -72,7 +72,7 @@ typedef struct {
                               sub-domains pass the GLOBAL tile colours so that every rank numbers its
                               phases alike (mmg_level_set_exchange_mode)        */
     int waves_per_tile;    /* 0: automatic; 1: one wavefront per tile, packed stream (the streaming layout of
-                              levels far larger than the device); 2, 4, 8: dense layout, that many wavefronts
+                              levels far larger than the device); 2, 3, 4, 6, 8: dense layout, that many wavefronts
                               share a tile and synchronise once per round of mutually uncoupled rows -- for
                               levels whose sweep is bound by the dependency chain of a tile, not by bytes   */
 } mmg_level_desc;
@@ -280,6 +280,31 @@ int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho);
 int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho);
 /* fs_residual  :152-154 */
 int mmg_fracstep_residual(mmg_fracstep *fs, double *value);
+/* 3-D (BASELINE configs[4]; the reference class is 2-D): operators 0 D_x, 1 D_y, 2 D_z, 3 velocity
+ * Laplacian; vectors `which` 4 = w, 5 = w_hat in addition to the four above; the predictor convects with
+ * (u, v, w), the PPE source is rho/dt (D_x u_hat + D_y v_hat + D_z w_hat) with n . grad p on the boundary,
+ * the corrector also updates w.  The 2-D entry points above are unchanged. */
+int mmg_fracstep_create_3d(mmg_fracstep **out, mmg_level *p, int n, const int *const op_rowptr[4],
+                           const int *const op_col[4], const double *const op_val[4], const double *nx, const double *ny,
+                           const double *nz, const int *bpts, int nbpts);
+/* FractionalStepGrid::set_uv_bound (:41-59): boundary velocities, one value per boundary point in the order
+ * of `bpts`; component 0 u, 1 v, 2 w.  _apply_bound scatters them into the device vectors. */
+int mmg_fracstep_set_bound_values(mmg_fracstep *fs, int component, const double *vals, int count);
+int mmg_fracstep_apply_bound(mmg_fracstep *fs);
+/* One time step of run_fracstep_param (FractionalStepSim.cpp:131-147), device-resident: set_uv_bound,
+ * calc_u_hat / calc_v_hat, set_ppe_source, push_inhomog_to_rhs, `while (mg.residual() >= tol) { mg.vCycle();
+ * finestGrid->bound_eval_neumann(); }` (at most max_cycles V-cycles), correct_u / correct_v, set_uv_bound,
+ * fs_residual.  `h` is the FractionalStepMultigrid whose finest level is the grid's pressure level.
+ * cycles (may be NULL): V-cycles taken; fs_resid (may be NULL): fs_residual() after the step. */
+int mmg_fracstep_step(mmg_fracstep *fs, mmg_hierarchy *h, double dt, double mu, double rho, double tol, int max_cycles,
+                      int *cycles, double *fs_resid);
+/* Grid::push_inhomog_to_rhs (grid.cpp:664-685).  _set_neumann_coupling registers neumann_boundary_coeffs_
+ * (row-major CSR over the n points: the interior-row entries of the operator in Neumann columns, before
+ * the implicit elimination) and the diagonal `diags` [n]; _push_inhomog_to_rhs then performs
+ * source_[i] -= A_ij * source_[j] / diags[j] over the Neumann neighbours j of every interior row i, from the
+ * right-hand side as it is at the call.  Without a registered coupling it is a no-op (implicitFlag_ false). */
+int mmg_level_set_neumann_coupling(mmg_level *lv, const int *rowptr, const int *col, const double *val, const double *diag);
+int mmg_level_push_inhomog_to_rhs(mmg_level *lv);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,8 @@ SYMBOLS = [
     "mmg_restrict", "mmg_prolong_add", "mmg_hierarchy_create", "mmg_hierarchy_destroy", "mmg_vcycle",
     "mmg_hierarchy_residual", "mmg_vcycles", "mmg_rbf_weights", "mmg_spmv_create", "mmg_spmv_destroy", "mmg_spmv_apply", "mmg_fracstep_create", "mmg_fracstep_destroy",
     "mmg_fracstep_set", "mmg_fracstep_get", "mmg_fracstep_calc_hat", "mmg_fracstep_set_ppe_source",
-    "mmg_fracstep_correct", "mmg_fracstep_residual",
+    "mmg_fracstep_correct", "mmg_fracstep_residual", "mmg_fracstep_create_3d", "mmg_fracstep_set_bound_values",
+    "mmg_fracstep_apply_bound", "mmg_fracstep_step", "mmg_level_set_neumann_coupling", "mmg_level_push_inhomog_to_rhs",
 ]
 
 _lib = None

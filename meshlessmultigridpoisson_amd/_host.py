@@ -571,14 +571,24 @@ def _jitter_hash(gid, axis, seed):
     return (z >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
 
 
-def slab_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25):
-    """Rank's part of a (nranks*nside) x nside [x nside] jittered lattice on [0,nranks]x[0,1]^(dim-1):
-    its own nside x-layers plus `margin` layers of each neighbour as ghost candidates.
+def slab_bounds(rank, nranks, nx_glob):
+    """x-layers [lo, hi) of rank's slab when nx_glob layers are shared as evenly as possible."""
+    base, rem = divmod(nx_glob, nranks)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def slab_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25, total=False):
+    """Rank's part of a jittered lattice cut into x-slabs: its own x-layers plus `margin` layers of each
+    neighbour as ghost candidates.  total = False (weak scaling): a (nranks*nside) x nside [x nside] lattice on
+    [0,nranks]x[0,1]^(dim-1), nside layers per rank.  total = True (strong scaling): ONE nside^dim lattice on the
+    unit cube, its nside layers shared evenly (slab_bounds).
     Returns (points, flags, gid, owner); flags 0 interior / 1 global Dirichlet boundary / 3 margin."""
     h = 1.0 / (nside - 1)
-    nx_glob = nranks * nside
-    lo = max(0, rank * nside - margin)
-    hi = min(nx_glob, (rank + 1) * nside + margin)
+    nx_glob = nside if total else nranks * nside
+    own_lo, own_hi = slab_bounds(rank, nranks, nx_glob)
+    lo = max(0, own_lo - margin)
+    hi = min(nx_glob, own_hi + margin)
     ix = np.arange(lo, hi)
     if dim == 3:
         IZ, IY, IX = np.meshgrid(np.arange(nside), np.arange(nside), ix, indexing="ij")
@@ -594,6 +604,7 @@ def slab_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25):
         bnd |= (idx[:, 2] == 0) | (idx[:, 2] == nside - 1)
     for a in range(dim):
         pts[~bnd, a] += _jitter_hash(gid[~bnd], a, seed) * jitter * h
-    owner = (idx[:, 0] // nside).astype(np.int32)
+    starts = np.array([slab_bounds(r, nranks, nx_glob)[0] for r in range(nranks)])
+    owner = (np.searchsorted(starts, idx[:, 0], side="right") - 1).astype(np.int32)
     flags = np.where(owner == rank, bnd.astype(np.int32), 3).astype(np.int32)
     return pts, flags, gid.astype(np.int32), owner

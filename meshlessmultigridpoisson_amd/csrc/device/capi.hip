@@ -209,7 +209,7 @@ struct PlanGpu {
         dev.n_tiles = P.n_tiles;
         dev.lds_bytes = (unsigned)P.lds_bytes();
         dev.lds_bytes_resident = (unsigned)std::min<size_t>(P.lds_bytes_resident(), 0xffffffffu);
-        dev.max_plen = P.max_plen;
+        dev.max_plen = P.dense ? P.dense_plen : P.max_plen;  // dense: the group shape, also for a plan without rows
         return MMG_OK;
     }
 };
@@ -282,6 +282,9 @@ struct mmg_level {
     DevBuf<int32_t> send_idx;
     DevBuf<double> sendbuf;
     DevBuf<double> scalS;  // all-reduced sum of the non-Neumann x (multiplier row)
+    // Grid::push_inhomog_to_rhs (mmg_level_set_neumann_coupling): interior-row entries in Neumann columns
+    PlanGpu C;
+    DevBuf<double> c_diag, c_s, c_t;
     // recovery from a dependency-driven launch whose bounded wait ran out (settle)
     DevBuf<double> x_backup;   // x in front of the unchecked sweeps
     int unsettled_sweeps = 0;  // > 0: sweeps of the last mmg_level_sor / _sweeps call, issued but not yet checked
@@ -307,12 +310,14 @@ struct mmg_hierarchy {
 
 struct mmg_fracstep {
     mmg_level *p = nullptr;
-    int n = 0;
-    PlanGpu dx, dy, lap;
-    DevBuf<double> w[4];       // u, v, u_hat, v_hat
-    DevBuf<double> t1, t2, t3;  // operator outputs
-    DevBuf<double> nx, ny, partial, scal;
+    int n = 0, dim = 2;
+    PlanGpu dx, dy, dz, lap;
+    DevBuf<double> w[6];       // u, v, u_hat, v_hat, w, w_hat (the last two: 3-D only)
+    DevBuf<double> t1, t2, t3, t4;  // operator outputs
+    DevBuf<double> nx, ny, nz, partial, scal;
     DevBuf<int32_t> bpts;
+    DevBuf<double> bound[3];   // velocity boundary values per boundary point (mmg_fracstep_set_bound_values)
+    bool has_bound[3] = {false, false, false};
 };
 
 struct mmg_spmv {
@@ -681,6 +686,22 @@ int modify_coeff_neumann(mmg_level *lv, int coarse)
     return MMG_OK;
 }
 
+// Grid::push_inhomog_to_rhs (grid.cpp:664-685): b_i -= sum_j A_ij b_j / a_jj over the Neumann neighbours j of
+// every interior row i -- s = b ./ diag on Neumann points, t = C s (gather plan), b -= t on interior points
+int push_inhomog(mmg_level *lv)
+{
+    if (lv->C.empty()) return MMG_OK;  // no coupling registered (implicitFlag_ false, grid.cpp:665)
+    HIPC(launch_div_masked(lv->c_s.p, lv->b.p, lv->c_diag.p, lv->flags8.p, lv->n, g_stream));
+    TileArgs a{};
+    a.p = lv->C.dev;
+    a.n_list = lv->C.n_tiles;
+    a.in = lv->c_s.p;
+    a.out = lv->c_t.p;
+    HIPC(run_tiles(lv->C, MODE_SET, a, g_stream));
+    HIPC(launch_sub_interior(lv->b.p, lv->c_t.p, lv->flags8.p, lv->n, g_stream));
+    return MMG_OK;
+}
+
 int upload_bvals(mmg_level *lv, const double *bvals)
 {
     std::vector<double> dv(lv->dir_idx_h.size()), nv(lv->neu_idx_h.size());
@@ -934,15 +955,28 @@ int mmg_device_props(int *compute_units, int *lds_bytes_per_cu)
 }  // extern "C"
 
 namespace {
-// Dense multi-wavefront layout or packed stream?  A sweep over the packed stream costs at least
-// phases x (one tile's dependency chain) ~ phases x 35 us however small the level; the dense layout runs the
-// chain ~5x faster but moves ~1.3x the bytes.  Dense wins while its bytes stream in less time than the
-// packed chain takes (3-D K = 50: below ~2e6 points; 2-D K = 37: below ~1.4e6).
-bool level_is_latency_bound(long long n_points, double avg_row_len)
+// Dense multi-wavefront layout or packed stream, and which shape?  A sweep over the packed stream costs at
+// least phases x (one tile's dependency chain) ~ phases x 40 us however small the level; the dense layout
+// runs the chain ~5x faster but moves 1.5-2x the bytes (row slots and entry slots that stay empty).
+// Measured crossovers (MI355X, us per sweep, dense vs packed): 3-D K = 50: 27^3 69 / 250, 54^3 86 / 290,
+// 108^3 217 / 382, 128^3 357 / 473, 150^3 510 / 553; 2-D K = 25: 500^2 39 / 57; 2-D K = 37: 1000^2 161 / 147.
+struct LevelLayout {
+    bool dense;
+    int tile_points, lanes, waves;
+};
+LevelLayout level_layout(long long n_points, double avg_row_len)
 {
-    const double phases = avg_row_len >= 44.0 ? 8.0 : 4.0;  // 3-D / 2-D tile colourings of Grid::mc_order_points
-    const double dense_bytes = (double)n_points * (12.0 * avg_row_len + 28.0) * 1.3;
-    return dense_bytes / 6.0e12 < phases * 35e-6;
+    if (avg_row_len >= 44.0) {  // 3-D stencils (K = 50): 8 tile colours, ~23 dependency levels per tile
+        if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows
+        if (n_points <= 3000000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217 us)
+        return {false, 0, 0, 1};
+    }
+    if (avg_row_len <= 30.0) {  // 2-D K = 25 (the coarse levels of the reference's hierarchies)
+        if (n_points <= 600000) return {true, 256, 8, 3};
+        return {false, 0, 0, 1};
+    }
+    if (n_points <= 300000) return {true, 256, 8, 4};          // 2-D K = 37 ... 70
+    return {false, 0, 0, 1};
 }
 }  // namespace
 
@@ -951,7 +985,11 @@ extern "C" {
 int mmg_auto_tile_points(long long n_points, int dim, int stencil, int lanes_per_row, int compute_units,
                          int lds_bytes_per_cu)
 {
-    if (g_waves != 1 && (g_waves > 1 || level_is_latency_bound(n_points, (double)stencil))) return 256;  // dense layout: short chains, many tiles
+    if (g_waves != 1) {  // dense layout (automatic, or forced by mmg_set_option("waves_per_tile")): its tile size
+        const LevelLayout ll = level_layout(n_points, (double)stencil);
+        if (ll.dense) return ll.tile_points;
+        if (g_waves > 1) return 256;
+    }
     if (compute_units <= 0 || lds_bytes_per_cu <= 0) {
         compute_units = 256;       // MI355X
         lds_bytes_per_cu = 163840;
@@ -1058,9 +1096,15 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
         Plan P;
         const double avg_row = (double)d->rowptr[d->n] / std::max(1, d->n);
         int waves = d->waves_per_tile > 0 ? d->waves_per_tile : g_waves;
-        if (waves <= 0) waves = level_is_latency_bound(d->n, avg_row) ? 4 : 1;
-        if (!(waves == 1 || waves == 2 || waves == 4 || waves == 8)) return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 4 or 8");
-        const std::string err = build_level_plan(*d, L, &P, g_exact, g_slot_bits, waves);
+        mmg_level_desc dd = *d;  // the automatic layout also picks the lanes per row of its dense shape
+        if (waves <= 0) {
+            const LevelLayout ll = level_layout(d->n, avg_row);
+            waves = ll.dense ? ll.waves : 1;
+            if (ll.dense && d->lanes_per_row <= 0) dd.lanes_per_row = ll.lanes;
+        }
+        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8))
+            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4, 6 or 8");
+        const std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;
         if ((rc = lv->A.upload(P))) return rc;
@@ -1224,6 +1268,32 @@ int mmg_level_modify_coeff_neumann(mmg_level *lv, int coarse)
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
     if (int src_ = settle(lv)) return src_;
     return modify_coeff_neumann(lv, coarse);
+}
+int mmg_level_set_neumann_coupling(mmg_level *lv, const int *rowptr, const int *col, const double *val, const double *diag)
+{
+    if (!lv || !rowptr || !diag) return fail(MMG_ERR_INVALID, "set_neumann_coupling: null argument");
+    if (int src_ = settle(lv)) return src_;
+    const int n = lv->n;
+    std::vector<int32_t> rows;
+    for (int i = 0; i < n; ++i)
+        if (rowptr[i + 1] > rowptr[i]) rows.push_back(i);
+    lv->C.n_rows = 0;
+    HIPC(lv->c_diag.upload(diag, (size_t)n));
+    HIPC(lv->c_s.alloc((size_t)n));
+    HIPC(lv->c_t.alloc((size_t)n));
+    HIPC(hipMemset(lv->c_t.p, 0, sizeof(double) * (size_t)n));
+    if (rows.empty()) return MMG_OK;
+    if (!col || !val) return fail(MMG_ERR_INVALID, "set_neumann_coupling: null entries");
+    for (int p = 0; p < rowptr[n]; ++p)
+        if (col[p] < 0 || col[p] >= n) return fail(MMG_ERR_INVALID, "set_neumann_coupling: column out of range");
+    CsrView A{n, n, rowptr, col, val};
+    return build_gather_plan(A, rows, 4, 256, false, false, false, -1, &lv->C);
+}
+int mmg_level_push_inhomog_to_rhs(mmg_level *lv)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    if (int src_ = settle(lv)) return src_;
+    return push_inhomog(lv);
 }
 int mmg_level_zero_x(mmg_level *lv)
 {
@@ -1615,6 +1685,47 @@ int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cl
 }
 
 // ---- fractional-step grid --------------------------------------------------------------
+namespace {
+int fracstep_create(mmg_fracstep **out, mmg_level *p, int n, int dim, const int *const rowptr[4], const int *const col[4],
+                    const double *const val[4], const double *const nrm[3], const int *bpts, int nbpts)
+{
+    *out = nullptr;
+    int rc = ensure_device();
+    if (rc) return rc;
+    auto fs = std::make_unique<mmg_fracstep>();
+    fs->p = p;
+    fs->n = n;
+    fs->dim = dim;
+    std::vector<int32_t> rows((size_t)n);
+    for (int i = 0; i < n; ++i) rows[i] = i;
+    const int L = p->A.dev.dense ? 4 : p->A.dev.L;  // gather plans keep the packed layout
+    PlanGpu *plans[4] = {&fs->dx, &fs->dy, &fs->dz, &fs->lap};
+    for (int k = 0; k < 4; ++k) {
+        if (k == 2 && dim < 3) continue;
+        CsrView A{n, n, rowptr[k], col[k], val[k]};
+        if ((rc = build_gather_plan(A, rows, L, 256, false, false, false, -1, plans[k]))) return rc;
+    }
+    const int nvec = dim >= 3 ? 6 : 4;
+    for (int k = 0; k < nvec; ++k) {
+        HIPC(fs->w[k].alloc((size_t)n));
+        HIPC(hipMemset(fs->w[k].p, 0, sizeof(double) * (size_t)n));
+    }
+    DevBuf<double> *tmp[4] = {&fs->t1, &fs->t2, &fs->t3, &fs->t4};
+    for (int k = 0; k < (dim >= 3 ? 4 : 3); ++k) {
+        HIPC(tmp[k]->alloc((size_t)n));
+        HIPC(hipMemset(tmp[k]->p, 0, sizeof(double) * (size_t)n));
+    }
+    HIPC(fs->nx.upload(nrm[0], (size_t)n));
+    HIPC(fs->ny.upload(nrm[1], (size_t)n));
+    if (dim >= 3) HIPC(fs->nz.upload(nrm[2], (size_t)n));
+    HIPC(fs->bpts.upload(bpts, (size_t)nbpts));
+    HIPC(fs->partial.alloc((size_t)std::max(1, abs_sum_blocks(n))));
+    HIPC(fs->scal.alloc(1));
+    *out = fs.release();
+    return MMG_OK;
+}
+}  // namespace
+
 int mmg_fracstep_create(mmg_fracstep **out, mmg_level *p, int n, const int *dx_rowptr, const int *dx_col,
                         const double *dx_val, const int *dy_rowptr, const int *dy_col, const double *dy_val,
                         const int *lap_rowptr, const int *lap_col, const double *lap_val, const double *nx,
@@ -1622,49 +1733,36 @@ int mmg_fracstep_create(mmg_fracstep **out, mmg_level *p, int n, const int *dx_r
 {
     if (!out || !p || n < 1 || n != p->n || !dx_rowptr || !dy_rowptr || !lap_rowptr || !nx || !ny || nbpts < 0)
         return fail(MMG_ERR_INVALID, "fracstep_create: bad argument");
-    *out = nullptr;
-    int rc = ensure_device();
-    if (rc) return rc;
-    auto fs = std::make_unique<mmg_fracstep>();
-    fs->p = p;
-    fs->n = n;
-    std::vector<int32_t> rows((size_t)n);
-    for (int i = 0; i < n; ++i) rows[i] = i;
-    const int L = p->A.dev.L;
-    CsrView A1{n, n, dx_rowptr, dx_col, dx_val}, A2{n, n, dy_rowptr, dy_col, dy_val}, A3{n, n, lap_rowptr, lap_col, lap_val};
-    if ((rc = build_gather_plan(A1, rows, L, 256, false, false, false, -1, &fs->dx))) return rc;
-    if ((rc = build_gather_plan(A2, rows, L, 256, false, false, false, -1, &fs->dy))) return rc;
-    if ((rc = build_gather_plan(A3, rows, L, 256, false, false, false, -1, &fs->lap))) return rc;
-    for (auto &b : fs->w) {
-        HIPC(b.alloc((size_t)n));
-        HIPC(hipMemset(b.p, 0, sizeof(double) * (size_t)n));
-    }
-    HIPC(fs->t1.alloc((size_t)n));
-    HIPC(fs->t2.alloc((size_t)n));
-    HIPC(fs->t3.alloc((size_t)n));
-    HIPC(hipMemset(fs->t1.p, 0, sizeof(double) * (size_t)n));
-    HIPC(hipMemset(fs->t2.p, 0, sizeof(double) * (size_t)n));
-    HIPC(hipMemset(fs->t3.p, 0, sizeof(double) * (size_t)n));
-    HIPC(fs->nx.upload(nx, (size_t)n));
-    HIPC(fs->ny.upload(ny, (size_t)n));
-    HIPC(fs->bpts.upload(bpts, (size_t)nbpts));
-    HIPC(fs->partial.alloc((size_t)std::max(1, abs_sum_blocks(n))));
-    HIPC(fs->scal.alloc(1));
-    *out = fs.release();
-    return MMG_OK;
+    const int *const rp[4] = {dx_rowptr, dy_rowptr, nullptr, lap_rowptr};
+    const int *const cl[4] = {dx_col, dy_col, nullptr, lap_col};
+    const double *const vl[4] = {dx_val, dy_val, nullptr, lap_val};
+    const double *const nr[3] = {nx, ny, nullptr};
+    return fracstep_create(out, p, n, 2, rp, cl, vl, nr, bpts, nbpts);
+}
+
+int mmg_fracstep_create_3d(mmg_fracstep **out, mmg_level *p, int n, const int *const op_rowptr[4],
+                           const int *const op_col[4], const double *const op_val[4], const double *nx, const double *ny,
+                           const double *nz, const int *bpts, int nbpts)
+{
+    if (!out || !p || n < 1 || n != p->n || !op_rowptr || !op_col || !op_val || !nx || !ny || !nz || nbpts < 0)
+        return fail(MMG_ERR_INVALID, "fracstep_create_3d: bad argument");
+    for (int k = 0; k < 4; ++k)
+        if (!op_rowptr[k] || !op_col[k] || !op_val[k]) return fail(MMG_ERR_INVALID, "fracstep_create_3d: null operator");
+    const double *const nr[3] = {nx, ny, nz};
+    return fracstep_create(out, p, n, 3, op_rowptr, op_col, op_val, nr, bpts, nbpts);
 }
 void mmg_fracstep_destroy(mmg_fracstep *fs) { delete fs; }
 
 int mmg_fracstep_set(mmg_fracstep *fs, int which, const double *w, int count)
 {
-    if (!fs || !w || which < 0 || which > 3 || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_set: bad argument");
+    if (!fs || !w || which < 0 || which >= (fs->dim >= 3 ? 6 : 4) || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_set: bad argument");
     HIPC(hipMemcpyAsync(fs->w[which].p, w, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;
 }
 int mmg_fracstep_get(mmg_fracstep *fs, int which, double *w, int count)
 {
-    if (!fs || !w || which < 0 || which > 3 || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_get: bad argument");
+    if (!fs || !w || which < 0 || which >= (fs->dim >= 3 ? 6 : 4) || count != fs->n) return fail(MMG_ERR_INVALID, "fracstep_get: bad argument");
     HIPC(hipMemcpyAsync(w, fs->w[which].p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
     return MMG_OK;
@@ -1688,6 +1786,19 @@ int mmg_fracstep_calc_hat(mmg_fracstep *fs, double dt, double mu, double rho)
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
     const double *u = fs->w[0].p, *v = fs->w[1].p;
+    if (fs->dim >= 3) {  // third component: (u, v, w) . grad also carries w d/dz
+        const int comp[3] = {0, 1, 4}, hat[3] = {2, 3, 5};
+        for (int c = 0; c < 3; ++c) {
+            const double *w = fs->w[comp[c]].p;
+            if ((rc = fs_apply(fs->dx, w, fs->t1.p))) return rc;
+            if ((rc = fs_apply(fs->dy, w, fs->t2.p))) return rc;
+            if ((rc = fs_apply(fs->dz, w, fs->t4.p))) return rc;
+            if ((rc = fs_apply(fs->lap, w, fs->t3.p))) return rc;
+            HIPC(launch_fs_hat3(fs->w[hat[c]].p, w, u, v, fs->w[4].p, fs->t1.p, fs->t2.p, fs->t4.p, fs->t3.p, dt, mu / rho,
+                                fs->n, g_stream));
+        }
+        return MMG_OK;
+    }
     for (int c = 0; c < 2; ++c) {
         const double *w = fs->w[c].p;
         if ((rc = fs_apply(fs->dx, w, fs->t1.p))) return rc;
@@ -1705,6 +1816,13 @@ int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho)
     if ((rc = settle(fs->p))) return rc;
     if ((rc = fs_apply(fs->dx, fs->w[2].p, fs->t1.p))) return rc;
     if ((rc = fs_apply(fs->dy, fs->w[3].p, fs->t2.p))) return rc;
+    if (fs->dim >= 3) {
+        if ((rc = fs_apply(fs->dz, fs->w[5].p, fs->t4.p))) return rc;
+        HIPC(launch_fs_ppe_interior3(fs->p->b.p, fs->t1.p, fs->t2.p, fs->t4.p, rho / dt, fs->n, g_stream));
+        HIPC(launch_fs_ppe_boundary3(fs->p->b.p, fs->bpts.p, (int)fs->bpts.n, fs->w[0].p, fs->w[1].p, fs->w[4].p, fs->w[2].p,
+                                     fs->w[3].p, fs->w[5].p, fs->nx.p, fs->ny.p, fs->nz.p, rho / dt, g_stream));
+        return MMG_OK;
+    }
     HIPC(launch_fs_ppe_interior(fs->p->b.p, fs->t1.p, fs->t2.p, rho / dt, fs->n, g_stream));
     HIPC(launch_fs_ppe_boundary(fs->p->b.p, fs->bpts.p, (int)fs->bpts.n, fs->w[0].p, fs->w[1].p, fs->w[2].p, fs->w[3].p,
                                 fs->nx.p, fs->ny.p, rho / dt, g_stream));
@@ -1720,6 +1838,74 @@ int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho)
     HIPC(launch_fs_correct(fs->w[0].p, fs->w[2].p, fs->t1.p, dt / rho, fs->n, g_stream));
     if ((rc = fs_apply(fs->dy, fs->p->x.p, fs->t2.p))) return rc;
     HIPC(launch_fs_correct(fs->w[1].p, fs->w[3].p, fs->t2.p, dt / rho, fs->n, g_stream));
+    if (fs->dim >= 3) {
+        if ((rc = fs_apply(fs->dz, fs->p->x.p, fs->t4.p))) return rc;
+        HIPC(launch_fs_correct(fs->w[4].p, fs->w[5].p, fs->t4.p, dt / rho, fs->n, g_stream));
+    }
+    return MMG_OK;
+}
+
+// velocity boundary data (FractionalStepGrid::set_uv_bound, fractionalStepGrid.cpp:41-59): values per
+// boundary point, in the order of the bpts handed to mmg_fracstep_create; component 0 u, 1 v, 2 w
+int mmg_fracstep_set_bound_values(mmg_fracstep *fs, int component, const double *vals, int count)
+{
+    if (!fs || !vals || component < 0 || component >= fs->dim || count != (int)fs->bpts.n)
+        return fail(MMG_ERR_INVALID, "fracstep_set_bound_values: bad argument");
+    HIPC(hipStreamSynchronize(g_stream));
+    HIPC(fs->bound[component].upload(vals, (size_t)count));
+    fs->has_bound[component] = true;
+    return MMG_OK;
+}
+
+namespace {
+int fs_apply_bound(mmg_fracstep *fs)
+{
+    const int comp[3] = {0, 1, 4};
+    for (int c = 0; c < fs->dim; ++c)
+        if (fs->has_bound[c])
+            HIPC(launch_scatter_vals(fs->w[comp[c]].p, fs->bpts.p, fs->bound[c].p, (int)fs->bpts.n, g_stream));
+    return MMG_OK;
+}
+}  // namespace
+
+int mmg_fracstep_apply_bound(mmg_fracstep *fs)
+{
+    if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
+    return fs_apply_bound(fs);
+}
+
+// One time step, device-resident (FractionalStepSim.cpp:131-147): boundary velocities, predictor, PPE source,
+// push_inhomog_to_rhs, `while (mg.residual() >= tol) { mg.vCycle(); finestGrid->bound_eval_neumann(); }`,
+// corrector, boundary velocities, fs_residual.  Host round trips: the residual scalars of the pressure loop
+// (the loop condition is a host decision in the reference as well) and the final fs_residual.
+int mmg_fracstep_step(mmg_fracstep *fs, mmg_hierarchy *h, double dt, double mu, double rho, double tol, int max_cycles,
+                      int *cycles, double *fs_resid)
+{
+    if (!fs || !h || h->lv.empty() || h->lv.back() != fs->p || max_cycles < 0)
+        return fail(MMG_ERR_INVALID, "fracstep_step: the hierarchy's finest level must be the fractional-step grid's level");
+    int rc;
+    mmg_level *fine = fs->p;
+    if ((rc = settle_hierarchy(h)) || (rc = settle(fine))) return rc;
+    if ((rc = fs_apply_bound(fs))) return rc;
+    if ((rc = mmg_fracstep_calc_hat(fs, dt, mu, rho))) return rc;
+    if ((rc = mmg_fracstep_set_ppe_source(fs, dt, rho))) return rc;
+    if ((rc = push_inhomog(fine))) return rc;
+    int nc = 0;
+    for (;;) {
+        double ratio = 0.0;
+        if ((rc = residual_ratio(fine, &ratio))) return rc;  // mg.residual()
+        if (!(ratio >= tol) || nc >= max_cycles) break;
+        double before = 0.0;
+        if ((rc = vcycle_dev(h, &before))) return rc;
+        if ((rc = bound_eval(fine))) return rc;
+        ++nc;
+    }
+    if (cycles) *cycles = nc;
+    if ((rc = mmg_fracstep_correct(fs, dt, rho))) return rc;
+    if ((rc = fs_apply_bound(fs))) return rc;
+    double r = 0.0;
+    if ((rc = mmg_fracstep_residual(fs, &r))) return rc;
+    if (fs_resid) *fs_resid = r;
     return MMG_OK;
 }
 

@@ -849,6 +849,42 @@ __global__ void k_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const 
     const double dpdy = -rod * (v[p] - vh[p]);
     b[p] = nx[p] * dpdx + ny[p] * dpdy;
 }
+// 3-D variants (third velocity component ww, D_z): separate kernels, the 2-D expressions above stay as they are
+__global__ void k_fs_hat3(double *wh, const double *w, const double *u, const double *v, const double *ww, const double *wx,
+                          const double *wy, const double *wz, const double *lap, double dt, double mor, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wh[i] = w[i] + dt * (-(u[i] * wx[i] + v[i] * wy[i] + ww[i] * wz[i]) + mor * lap[i]);
+}
+__global__ void k_fs_ppe_interior3(double *b, const double *a, const double *c, const double *d, double rod, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) b[i] = rod * (a[i] + c[i] + d[i]);
+}
+__global__ void k_fs_ppe_boundary3(double *b, const int32_t *bpts, int nb, const double *u, const double *v, const double *w,
+                                   const double *uh, const double *vh, const double *wh, const double *nx, const double *ny,
+                                   const double *nz, double rod)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const int p = bpts[k];
+    const double dpdx = -rod * (u[p] - uh[p]);
+    const double dpdy = -rod * (v[p] - vh[p]);
+    const double dpdz = -rod * (w[p] - wh[p]);
+    b[p] = nx[p] * dpdx + ny[p] * dpdy + nz[p] * dpdz;
+}
+// Grid::push_inhomog_to_rhs (grid.cpp:664-685) in two pointwise steps around one gather plan:
+// s_j = b_j / a_jj on the Neumann points (0 elsewhere);  b_i -= (C s)_i on the interior points
+__global__ void k_div_masked(double *s, const double *b, const double *diag, const uint8_t *flags8, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s[i] = flags8[i] == 2 ? b[i] / diag[i] : 0.0;
+}
+__global__ void k_sub_interior(double *b, const double *t, const uint8_t *flags8, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flags8[i] == 0) b[i] -= t[i];
+}
 __global__ void k_fs_correct(double *w, const double *wh, const double *g, double dor, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -897,6 +933,36 @@ hipError_t launch_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const 
 {
     if (nb <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_fs_ppe_boundary, dim3((nb + 255) / 256), dim3(256), 0, s, b, bpts, nb, u, v, uh, vh, nx, ny, rod);
+    return hipGetLastError();
+}
+hipError_t launch_fs_hat3(double *w_hat, const double *w, const double *u, const double *v, const double *ww,
+                          const double *wx, const double *wy, const double *wz, const double *lap, double dt, double mor, int n,
+                          hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fs_hat3, dim3((n + 255) / 256), dim3(256), 0, s, w_hat, w, u, v, ww, wx, wy, wz, lap, dt, mor, n);
+    return hipGetLastError();
+}
+hipError_t launch_fs_ppe_interior3(double *b, const double *a, const double *c, const double *d, double rod, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fs_ppe_interior3, dim3((n + 255) / 256), dim3(256), 0, s, b, a, c, d, rod, n);
+    return hipGetLastError();
+}
+hipError_t launch_fs_ppe_boundary3(double *b, const int32_t *bpts, int nb, const double *u, const double *v, const double *w,
+                                   const double *uh, const double *vh, const double *wh, const double *nx, const double *ny,
+                                   const double *nz, double rod, hipStream_t s)
+{
+    if (nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fs_ppe_boundary3, dim3((nb + 255) / 256), dim3(256), 0, s, b, bpts, nb, u, v, w, uh, vh, wh, nx, ny, nz, rod);
+    return hipGetLastError();
+}
+hipError_t launch_div_masked(double *sv, const double *b, const double *diag, const uint8_t *flags8, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_div_masked, dim3((n + 255) / 256), dim3(256), 0, s, sv, b, diag, flags8, n);
+    return hipGetLastError();
+}
+hipError_t launch_sub_interior(double *b, const double *t, const uint8_t *flags8, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sub_interior, dim3((n + 255) / 256), dim3(256), 0, s, b, t, flags8, n);
     return hipGetLastError();
 }
 hipError_t launch_fs_correct(double *w, const double *w_hat, const double *g, double dor, int n, hipStream_t s)

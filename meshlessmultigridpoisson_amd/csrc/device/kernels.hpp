@@ -125,6 +125,18 @@ hipError_t launch_fs_ppe_interior(double *b, const double *a, const double *c, d
 hipError_t launch_fs_ppe_boundary(double *b, const int32_t *bpts, int nb, const double *u, const double *v,
                                   const double *uh, const double *vh, const double *nx, const double *ny,
                                   double rho_over_dt, hipStream_t s);
+// 3-D: w_hat = w + dt * (-(u*wx + v*wy + ww*wz) + mu/rho * lap);  b = rho/dt * (a + c + d);  boundary with n_z
+hipError_t launch_fs_hat3(double *w_hat, const double *w, const double *u, const double *v, const double *ww,
+                          const double *wx, const double *wy, const double *wz, const double *lap, double dt,
+                          double mu_over_rho, int n, hipStream_t s);
+hipError_t launch_fs_ppe_interior3(double *b, const double *a, const double *c, const double *d, double rho_over_dt, int n,
+                                   hipStream_t s);
+hipError_t launch_fs_ppe_boundary3(double *b, const int32_t *bpts, int nb, const double *u, const double *v, const double *w,
+                                   const double *uh, const double *vh, const double *wh, const double *nx, const double *ny,
+                                   const double *nz, double rho_over_dt, hipStream_t s);
+// s = b / diag on Neumann points (flags8 == 2), 0 elsewhere;  b -= t on interior points (flags8 == 0)
+hipError_t launch_div_masked(double *s_out, const double *b, const double *diag, const uint8_t *flags8, int n, hipStream_t s);
+hipError_t launch_sub_interior(double *b, const double *t, const uint8_t *flags8, int n, hipStream_t s);
 // w = w_hat - dt_over_rho * g
 hipError_t launch_fs_correct(double *w, const double *w_hat, const double *g, double dt_over_rho, int n, hipStream_t s);
 // partial[block] = sum |a - b|

@@ -393,7 +393,9 @@ hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t 
 {
     switch (a.p.waves) {
     case 2: return launch_mw_LPN<L, P, 2>(k, a, workers, s, occ);
+    case 3: return launch_mw_LPN<L, P, 3>(k, a, workers, s, occ);
     case 4: return launch_mw_LPN<L, P, 4>(k, a, workers, s, occ);
+    case 6: return launch_mw_LPN<L, P, 6>(k, a, workers, s, occ);
     case 8: return launch_mw_LPN<L, P, 8>(k, a, workers, s, occ);
     }
     return hipErrorInvalidValue;

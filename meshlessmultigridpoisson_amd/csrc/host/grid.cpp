@@ -1,6 +1,7 @@
 // grid.cpp -- see grid.h.  Setup follows MeshlessPoisson/grid.cpp (citations per
 // method); the hot methods forward to the C-ABI of libmmgp.so.
 #include "grid.h"
+#include <memory>
 
 #include <algorithm>
 #include <atomic>
@@ -344,13 +345,16 @@ bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *eval
     ensure_knn();
     nbr.assign((size_t)ne * (size_t)ss, 0);
     std::atomic<int> short_rows{0};
+    std::unique_ptr<mmgh::SetupTimer> tk(new mmgh::SetupTimer("batched_stencils: kNN (host)"));
     parallel_for((int)ne, threads(), [&](int e) {
         const bool isb = evalIsBoundary ? (*evalIsBoundary)[(size_t)e] != 0 : false;
         const vector<int> nb = kNearestNeighbors(evals[(size_t)e], neumann, isb, ss);
         if ((int)nb.size() != ss) { short_rows++; return; }
         std::copy(nb.begin(), nb.end(), nbr.begin() + (size_t)e * (size_t)ss);
     });
+    tk.reset();
     if (short_rows.load() > 0) return false;  // fewer candidates than the stencil wants: host path decides
+    mmgh::SetupTimer tw("batched_stencils: weights (device)");
     std::vector<double> cloud(points_.size() * 3), ev((size_t)ne * 3);
     for (size_t i = 0; i < points_.size(); ++i) {
         cloud[3 * i] = std::get<0>(points_[i]);
@@ -372,6 +376,7 @@ bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *eval
 // grid.cpp:549-663
 void Grid::build_laplacian()
 {
+    mmgh::SetupTimer tt("build_laplacian (total)");
     invalidate_device();
     const int n = laplaceMatSize_;
     ensure_knn();
@@ -790,6 +795,7 @@ void Grid::invalidate_device()
 mmg_level *Grid::device()
 {
     if (dev_) return dev_;
+    mmgh::SetupTimer tt("Grid::device: mmg_level_create");
     mmg_level_desc d{};
     d.n = laplaceMatSize_;
     d.a_size = laplaceMat_->rows();

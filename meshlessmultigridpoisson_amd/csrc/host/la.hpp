@@ -10,6 +10,9 @@
 // from the device when the device copy is newer, writes mark the host copy
 // newer ("lazy download on access").
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -250,5 +253,19 @@ inline void full_piv_lu_solve(Mat a, std::vector<std::vector<double>> &rhs)
         for (int k = 0; k < n; ++k) b[(size_t)colperm[k]] = y[k];
     }
 }
+
+
+// wall-clock stamps of the setup stages on stderr when MMG_VERBOSE is set (development aid)
+struct SetupTimer {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit SetupTimer(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~SetupTimer()
+    {
+        if (std::getenv("MMG_VERBOSE"))
+            std::fprintf(stderr, "[setup] %-34s %8.3f s\n", what,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 }  // namespace mmgh

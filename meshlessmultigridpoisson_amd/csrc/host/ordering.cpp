@@ -93,15 +93,19 @@ void Grid::mc_order_points(int tile_points)
     const int n = (int)points_.size();
     if (tile_points <= 0) tile_points = mmg_auto_tile_points(nOwned_ >= 0 ? nOwned_ : n, dim_, properties_.stencilSize, lanes_per_row_, 0, 0);
     if (tile_points < 8) tile_points = 8;
+    mmgh::SetupTimer tt("mc_order_points (total)");
     ensure_knn();
     const int nth = threads();
 
     // ---- predicted coupling graph (same construction as rcm_order_points) -------
     vector<vector<int>> adj((size_t)n);
-    par_for(n, nth, [&](int i) {
-        if (bcFlags_[(size_t)i] == kGhost) return;
-        adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
-    });
+    {
+        mmgh::SetupTimer tk("mc_order_points: kNN graph");
+        par_for(n, nth, [&](int i) {
+            if (bcFlags_[(size_t)i] == kGhost) return;
+            adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
+        });
+    }
     if (neumannFlag_ && implicitFlag_) {
         for (int i = 0; i < n; ++i) {
             if (bcFlags_[(size_t)i] != 0) continue;

@@ -339,3 +339,90 @@ double orc_fs_residual(int n, const double *u, const double *u_hat)
     for (int i = 0; i < n; ++i) s += fabs(u[i] - u_hat[i]);
     return s / n;
 }
+
+/* ======================================================================================
+ * 3-D fractional step (BASELINE configs[4]).  The reference's FractionalStepGrid is 2-D; the three
+ * functions below are the same statements with the third velocity component, D_z and n_z added
+ * (fractionalStepGrid.cpp:101-151 extended; no reference counterpart, hence no reference fixture).
+ * ==================================================================================== */
+void orc_fs_calc_hat3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const orc_csr *lap,
+                      const double *u, const double *v, const double *w, double dt, double mu, double rho,
+                      double *u_hat, double *v_hat, double *w_hat)
+{
+    double *fx = (double *)malloc(sizeof(double) * (size_t)n);
+    double *fy = (double *)malloc(sizeof(double) * (size_t)n);
+    double *fz = (double *)malloc(sizeof(double) * (size_t)n);
+    double *l2 = (double *)malloc(sizeof(double) * (size_t)n);
+    const double *c[3] = {u, v, w};
+    double *h[3] = {u_hat, v_hat, w_hat};
+    for (int k = 0; k < 3; ++k) {
+        orc_csr_spmv(dx, c[k], fx);
+        orc_csr_spmv(dy, c[k], fy);
+        orc_csr_spmv(dz, c[k], fz);
+        orc_csr_spmv(lap, c[k], l2);
+        for (int i = 0; i < n; ++i)
+            h[k][i] = c[k][i] + dt * (-(u[i] * fx[i] + v[i] * fy[i] + w[i] * fz[i]) + mu / rho * l2[i]);
+    }
+    free(fx);
+    free(fy);
+    free(fz);
+    free(l2);
+}
+
+void orc_fs_set_ppe_source3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const double *u,
+                            const double *v, const double *w, const double *u_hat, const double *v_hat,
+                            const double *w_hat, double dt, double rho, const int *bpts, int nbpts, const double *nx,
+                            const double *ny, const double *nz, double *source)
+{
+    double *a = (double *)malloc(sizeof(double) * (size_t)n);
+    double *b = (double *)malloc(sizeof(double) * (size_t)n);
+    double *c = (double *)malloc(sizeof(double) * (size_t)n);
+    orc_csr_spmv(dx, u_hat, a);
+    orc_csr_spmv(dy, v_hat, b);
+    orc_csr_spmv(dz, w_hat, c);
+    for (int i = 0; i < n; ++i) source[i] = rho / dt * (a[i] + b[i] + c[i]);
+    for (int k = 0; k < nbpts; ++k) {
+        const int p = bpts[k];
+        const double dpdx = -rho / dt * (u[p] - u_hat[p]);
+        const double dpdy = -rho / dt * (v[p] - v_hat[p]);
+        const double dpdz = -rho / dt * (w[p] - w_hat[p]);
+        source[p] = nx[p] * dpdx + ny[p] * dpdy + nz[p] * dpdz;
+    }
+    free(a);
+    free(b);
+    free(c);
+}
+
+void orc_fs_correct3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const double *p,
+                     const double *u_hat, const double *v_hat, const double *w_hat, double dt, double rho, double *u,
+                     double *v, double *w)
+{
+    double *g = (double *)malloc(sizeof(double) * (size_t)n);
+    orc_csr_spmv(dx, p, g);
+    for (int i = 0; i < n; ++i) u[i] = u_hat[i] - dt / rho * g[i];
+    orc_csr_spmv(dy, p, g);
+    for (int i = 0; i < n; ++i) v[i] = v_hat[i] - dt / rho * g[i];
+    orc_csr_spmv(dz, p, g);
+    for (int i = 0; i < n; ++i) w[i] = w_hat[i] - dt / rho * g[i];
+    free(g);
+}
+
+/* Grid::push_inhomog_to_rhs, grid.cpp:664-685: with implicit elimination of the Neumann unknowns the
+ * boundary data moves into the interior right-hand sides: b_i -= A_ij * b_j / a_jj over the Neumann
+ * neighbours j of interior row i (bc = neumann_boundary_coeffs_, the interior-row entries in Neumann
+ * columns; copy = the right-hand side before the call). */
+void orc_push_inhomog(int n, const orc_csr *bc, const double *diags, const int *bcflags, double *source)
+{
+    double *copy = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(copy, source, sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (bcflags[i] != 0) continue;
+        for (int p = bc->rowptr[i]; p < bc->rowptr[i + 1]; ++p) {
+            const double diag = diags[bc->col[p]];
+            const double a_ij = bc->val[p];
+            source[i] -= a_ij * copy[bc->col[p]] / diag;
+        }
+    }
+    free(copy);
+}
+

@@ -96,6 +96,18 @@ void orc_fs_set_ppe_source(int n, const orc_csr *dx, const orc_csr *dy, const do
 void orc_fs_correct(int n, const orc_csr *dx, const orc_csr *dy, const double *p, const double *u_hat,
                     const double *v_hat, double dt, double rho, double *u, double *v);
 double orc_fs_residual(int n, const double *u, const double *u_hat);
+/* 3-D extension (no reference counterpart) and Grid::push_inhomog_to_rhs (grid.cpp:664-685) */
+void orc_fs_calc_hat3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const orc_csr *lap,
+                      const double *u, const double *v, const double *w, double dt, double mu, double rho,
+                      double *u_hat, double *v_hat, double *w_hat);
+void orc_fs_set_ppe_source3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const double *u,
+                            const double *v, const double *w, const double *u_hat, const double *v_hat,
+                            const double *w_hat, double dt, double rho, const int *bpts, int nbpts, const double *nx,
+                            const double *ny, const double *nz, double *source);
+void orc_fs_correct3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const double *p,
+                     const double *u_hat, const double *v_hat, const double *w_hat, double dt, double rho, double *u,
+                     double *v, double *w);
+void orc_push_inhomog(int n, const orc_csr *bc, const double *diags, const int *bcflags, double *source);
 #ifdef __cplusplus
 }
 #endif

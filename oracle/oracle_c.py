@@ -79,6 +79,12 @@ def lib(fast=False):
         L.orc_fs_correct.argtypes = [C.c_int, pc, pc, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
         L.orc_fs_residual.argtypes = [C.c_int, _dp, _dp]
         L.orc_fs_residual.restype = C.c_double
+        L.orc_fs_calc_hat3.argtypes = [C.c_int, pc, pc, pc, pc, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                       _dp, _dp, _dp]
+        L.orc_fs_set_ppe_source3.argtypes = [C.c_int, pc, pc, pc, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
+                                             _ip, C.c_int, _dp, _dp, _dp, _dp]
+        L.orc_fs_correct3.argtypes = [C.c_int, pc, pc, pc, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp]
+        L.orc_push_inhomog.argtypes = [C.c_int, pc, _dp, _ip, _dp]
         _libs[name] = L
     return _libs[name]
 
@@ -282,3 +288,44 @@ class FracStep:
 
     def residual(self):
         return float(lib().orc_fs_residual(self.n, _pd(self.u), _pd(self.u_hat)))
+
+
+class FracStep3(FracStep):
+    """The 3-D extension (mmg_oracle.c: orc_fs_*3): third velocity component, D_z, n_z."""
+
+    def __init__(self, n, dx, dy, dz, lap, nx, ny, nz, bpts):
+        super().__init__(n, dx, dy, lap, nx, ny, bpts)
+        rp, col, val = _i(dz[0]), _i(dz[1]), _d(dz[2])
+        st = _Csr()
+        st.rows, st.rowptr, st.col, st.val = self.n, _pi(rp), _pi(col), _pd(val)
+        self._dz = (st, rp, col, val)
+        self.nz = _d(nz)
+        self.w, self.w_hat = np.zeros(self.n), np.zeros(self.n)
+
+    def calc_hat(self, dt, mu, rho):
+        lib().orc_fs_calc_hat3(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), C.byref(self._dz[0]),
+                               C.byref(self._m[2][0]), _pd(self.u), _pd(self.v), _pd(self.w), dt, mu, rho,
+                               _pd(self.u_hat), _pd(self.v_hat), _pd(self.w_hat))
+
+    def set_ppe_source(self, source, dt, rho):
+        lib().orc_fs_set_ppe_source3(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), C.byref(self._dz[0]),
+                                     _pd(self.u), _pd(self.v), _pd(self.w), _pd(self.u_hat), _pd(self.v_hat),
+                                     _pd(self.w_hat), dt, rho, _pi(self.bpts), len(self.bpts), _pd(self.nx), _pd(self.ny),
+                                     _pd(self.nz), _pd(source))
+
+    def correct(self, p, dt, rho):
+        p = _d(p)
+        lib().orc_fs_correct3(self.n, C.byref(self._m[0][0]), C.byref(self._m[1][0]), C.byref(self._dz[0]), _pd(p),
+                              _pd(self.u_hat), _pd(self.v_hat), _pd(self.w_hat), dt, rho, _pd(self.u), _pd(self.v),
+                              _pd(self.w))
+
+
+def push_inhomog(n, bc_csr, diags, bcflags, source):
+    """Grid::push_inhomog_to_rhs (grid.cpp:664-685) in place on `source` (float64 array of >= n entries)."""
+    rp, col, val = _i(bc_csr[0]), _i(bc_csr[1]), _d(bc_csr[2])
+    st = _Csr()
+    st.rows, st.rowptr, st.col, st.val = int(n), _pi(rp), _pi(col), _pd(val)
+    diags, bcflags = _d(diags), _i(bcflags)
+    assert source.dtype == np.float64 and source.flags["C_CONTIGUOUS"]
+    lib().orc_push_inhomog(int(n), C.byref(st), _pd(diags), _pi(bcflags), _pd(source))
+

@@ -68,7 +68,11 @@ def test_auto_tile_points_is_device_free_arithmetic():
     # device-filling level: largest multiple of 256 that keeps 4 wavefronts per CU (single dependency-driven launch)
     assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 1280
     assert _capi.auto_tile_points(10077696, 3, 50, 0, 256, 163840) == 1280  # lanes 0: as mmg_level_create picks L
-    assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 256  # one residency round per phase
+    # latency-bound levels take the dense multi-wavefront layout (capi.hip: level_layout): its tile sizes
+    assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 512
+    assert _capi.auto_tile_points(54 ** 3, 3, 50, 0, 256, 163840) == 256
+    assert _capi.auto_tile_points(250000, 2, 25, 0, 256, 163840) == 256
+    assert _capi.auto_tile_points(1000000, 2, 37, 0, 256, 163840) == 256  # packed stream, one residency round per phase
     # mid-size levels are bound by 8 phases x one tile's duration: small tiles (measured 171^3, 190^3)
     assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 384
     assert _capi.auto_tile_points(190 ** 3, 3, 50, 0, 256, 163840) == 384
