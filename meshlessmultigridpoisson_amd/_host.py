@@ -83,6 +83,14 @@ def lib():
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_fs_create_square.restype = vp
         L.mmgh_fs_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.mmgh_fs_create_box.restype = vp
+        L.mmgh_fs_create_box.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        L.mmgh_mg_create_fs.restype = vp
+        L.mmgh_mg_create_fs.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.mmgh_mg_fs_step.argtypes = [vp, C.c_int, _ip, _dp]
+        L.mmgh_grid_coupling_nnz.argtypes = [vp]
+        L.mmgh_grid_coupling_get.argtypes = [vp, _ip, _ip, _dp, _dp]
+        L.mmgh_fs_get_normal_z.argtypes = [vp, _dp]
         L.mmgh_fs_op_nnz.argtypes = [vp, C.c_int]
         L.mmgh_fs_op_get.argtypes = [vp, C.c_int, _ip, _ip, _dp]
         L.mmgh_fs_get_normals.argtypes = [vp, _dp, _dp]
@@ -349,16 +357,36 @@ class FracStepGrid(Grid):
     call sequence of genFractionalStepGrid (FractionalStepSim.cpp:3-49)."""
 
     @classmethod
-    def create(cls, points, polydeg=3, dt=2e-4, mu=0.025, rho=1.0, ordering=ORDER_MC, tile_points=0, coarse=False):
+    def create(cls, points, polydeg=3, dt=2e-4, mu=0.025, rho=1.0, ordering=ORDER_MC, tile_points=0, coarse=False, dim=2):
+        """dim 2: the reference's Kovasznay set-up (FractionalStepSim.cpp:3-49); dim 3: the 3-D extension on a
+        box cloud (third velocity component, D_z; Taylor-Green-shaped velocity data)."""
         pts = _d(points).reshape(-1, 3)
-        h = lib().mmgh_fs_create_square(len(pts), pts.ctypes.data_as(_dp), polydeg, dt, mu, rho, ordering, tile_points,
-                                        int(coarse))
+        if dim == 2:
+            h = lib().mmgh_fs_create_square(len(pts), pts.ctypes.data_as(_dp), polydeg, dt, mu, rho, ordering, tile_points,
+                                            int(coarse))
+        else:
+            h = lib().mmgh_fs_create_box(len(pts), pts.ctypes.data_as(_dp), int(dim), polydeg, dt, mu, rho, ordering,
+                                         tile_points, int(coarse))
         if not h:
             raise HostError(_err())
         g = cls(h)
         g._own = True
-        g.dt, g.mu, g.rho = dt, mu, rho
+        g.dt, g.mu, g.rho, g.dim = dt, mu, rho, dim
         return g
+
+    def normal_z(self):
+        nz = np.zeros(self.sizes()["n"])
+        lib().mmgh_fs_get_normal_z(self.h, nz.ctypes.data_as(_dp))
+        return nz
+
+    def coupling(self):
+        """(rowptr, col, val), diag: neumann_boundary_coeffs_ and diags behind Grid::push_inhomog_to_rhs."""
+        n = self.sizes()["n"]
+        nnz = lib().mmgh_grid_coupling_nnz(self.h)
+        rp, col, val, dg = np.zeros(n + 2, dtype=np.int32), np.zeros(max(nnz, 1), dtype=np.int32), np.zeros(max(nnz, 1)), np.zeros(n)
+        lib().mmgh_grid_coupling_get(self.h, rp.ctypes.data_as(_ip), col.ctypes.data_as(_ip), val.ctypes.data_as(_dp),
+                                     dg.ctypes.data_as(_dp))
+        return (rp[:n + 1], col[:nnz], val[:nnz]), dg
 
     def op(self, which):
         n = self.sizes()["n"]
@@ -506,6 +534,33 @@ class Multigrid:
         v = C.c_double(0)
         _chk(lib().mmgh_mg_residual(self.h, C.byref(v)))
         return v.value
+
+
+class FracStepMultigrid(Multigrid):
+    """run_fracstep_param's hierarchy (FractionalStepSim.cpp:115-121): a FractionalStepMultigrid over
+    FractionalStepGrids; `step()` is one device-resident time step (mmg_fracstep_step)."""
+
+    def __init__(self, clouds, polydegs, dim=2, dt=2e-4, mu=0.025, rho=1.0, ordering=ORDER_MC, tile_points=0):
+        npts = _i([len(c) for c in clouds])
+        xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))
+        pd = _i(polydegs)
+        self.h = lib().mmgh_mg_create_fs(len(clouds), npts.ctypes.data_as(_ip), xyz.ctypes.data_as(_dp),
+                                         pd.ctypes.data_as(_ip), int(dim), dt, mu, rho, ordering, tile_points)
+        if not self.h:
+            raise HostError(_err())
+        self.omega, self.iters, self.frac_step, self.residuals = 1.4, 5, True, []
+        self.dt, self.mu, self.rho, self.dim = dt, mu, rho, dim
+
+    def fs_grid(self):
+        g = FracStepGrid(lib().mmgh_mg_grid(self.h, self.nlevels - 1), owner=self)
+        g.dt, g.mu, g.rho, g.dim = self.dt, self.mu, self.rho, self.dim
+        return g
+
+    def step(self, max_cycles=1000):
+        """-> (fs_residual, V-cycles taken)"""
+        nc, r = C.c_int(0), C.c_double(0)
+        _chk(lib().mmgh_mg_fs_step(self.h, int(max_cycles), C.byref(nc), C.byref(r)))
+        return r.value, nc.value
 
 
 # ---- synthetic clouds (vectorised; seeds per SURVEY 8d) ------------------------------------

@@ -322,6 +322,35 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     };
 
     if (n_groups) hi = gh[gi];  // from here on the heads come from LDS
+    if constexpr (DEPTH == 2) {
+        // Two register sets (the streaming configuration of the large levels): no group is requested twice.
+        // While two more groups exist both issues of a trip are unconditional -- no join between an issue and
+        // the finish() before it; the last one or two groups are finished after the loop.  (Same-box A/B at
+        // 1e7 points: re-requesting the last group of every tile, as the clamped scheme below does, costs 4 %.)
+        uint32_t g = 0;
+        auto advance = [&]() {
+            pi += group_bytes_dev<BITS>(L, (int)(hi & 0xffu), (int)(hi >> 8));
+            ++gi;
+            hi = gh[gi < n_groups ? gi : n_groups - 1];
+        };
+        // on entry: r[0] holds group 0, the issue front stands at group 1 (prologue above; clamped if n_groups == 1)
+        while (g + 2 < n_groups) {
+            issue_group<L, MAXP, BITS, !LDSS>(pi, hi, lane, a.zeros, r[1]);
+            advance();
+            finish(r[0]);
+            issue_group<L, MAXP, BITS, !LDSS>(pi, hi, lane, a.zeros, r[0]);
+            advance();
+            finish(r[1]);
+            g += 2;
+        }
+        if (g + 1 < n_groups) {  // two groups left: r[0] holds g
+            issue_group<L, MAXP, BITS, !LDSS>(pi, hi, lane, a.zeros, r[1]);
+            finish(r[0]);
+            finish(r[1]);
+        } else if (g < n_groups) {
+            finish(r[0]);
+        }
+    } else {
     // Full trips of DEPTH groups: one back edge, no exit inside (an early exit makes the compiler route all
     // exits through a shared latch whose merged wait state drains the pipeline once per trip).  The last
     // n_groups % DEPTH groups are in flight when the loop ends (issue front clamped): finished without issues.
@@ -340,6 +369,7 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 #pragma unroll
     for (int j = 0; j < DEPTH - 1; ++j)
         if ((uint32_t)j < n_rem) finish(r[j]);
+    }
 #ifdef MMG_DEBUG_TIMING
     if (dbg && lane == 0) g_dbg[2] = wall_clock64();
     if (dbt) g_dbg_tiles[tile * 4 + 2] = wall_clock64();

@@ -1,5 +1,6 @@
 // fractionalStepGrid.cpp -- see fractionalStepGrid.hpp.
 #include "fractionalStepGrid.hpp"
+#include "multigrid.h"
 
 #include <atomic>
 #include <cmath>
@@ -31,14 +32,21 @@ FractionalStepGrid::FractionalStepGrid(vector<Point> points, vector<Boundary> bo
     v_old = new VectorXd(n);
     u_hat = new VectorXd(n);
     v_hat = new VectorXd(n);
+    w = new VectorXd(n);
+    w_old = new VectorXd(n);
+    w_hat = new VectorXd(n);
 }
 
 FractionalStepGrid::~FractionalStepGrid()
 {
     if (fs_) {
-        for (VectorXd *w : {u, v, u_hat, v_hat}) w->detach();
+        for (VectorXd *x : {u, v, u_hat, v_hat, w, w_hat}) x->detach();
         mmg_fracstep_destroy(fs_);
     }
+    delete w;
+    delete w_old;
+    delete w_hat;
+    delete derivZMat_;
     delete u_hat;
     delete v_hat;
     delete u;
@@ -50,9 +58,32 @@ FractionalStepGrid::~FractionalStepGrid()
     delete uvLaplaceMat_;
 }
 
+namespace {
+// 3-D stand-in for the Kovasznay field (the reference has no 3-D flow): a smooth divergence-free velocity
+// (Taylor-Green shape) whose boundary values are non-trivial on every face of the unit cube
+void tg3(double x, double y, double z, double *uu, double *vv, double *ww)
+{
+    *uu = std::sin(MMG_PI * x) * std::cos(MMG_PI * y) * std::cos(MMG_PI * z);
+    *vv = -0.5 * std::cos(MMG_PI * x) * std::sin(MMG_PI * y) * std::cos(MMG_PI * z);
+    *ww = -0.5 * std::cos(MMG_PI * x) * std::cos(MMG_PI * y) * std::sin(MMG_PI * z);
+}
+}  // namespace
+
 // fractionalStepGrid.cpp:26-40 -- Kovasznay flow, Re = rho/mu
 void FractionalStepGrid::prescribe_soln()
 {
+    if (dim_ >= 3) {
+        for (int i = 0; i < laplaceMatSize_; ++i) {
+            double uu, vv, ww;
+            tg3(std::get<0>(points_[(size_t)i]), std::get<1>(points_[(size_t)i]), std::get<2>(points_[(size_t)i]), &uu, &vv, &ww);
+            u->coeffRef(i) = u_old->coeffRef(i) = uu;
+            v->coeffRef(i) = v_old->coeffRef(i) = vv;
+            w->coeffRef(i) = w_old->coeffRef(i) = ww;
+            values_->coeffRef(i) = 0.0;
+        }
+        values_->coeffRef(laplaceMatSize_) = 0;
+        return;
+    }
     const double re = rho / mu;
     lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * MMG_PI * MMG_PI);
     for (int i = 0; i < laplaceMatSize_; ++i) {
@@ -73,6 +104,18 @@ void FractionalStepGrid::set_uv_bound()
 {
     const double re = rho / mu;
     lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * MMG_PI * MMG_PI);
+    if (dim_ >= 3) {
+        if (flowType.compare("taylor_green_3d") != 0) return;
+        for (const Boundary &b : boundaries_)
+            for (int p : b.bcPoints) {
+                double uu, vv, ww;
+                tg3(std::get<0>(points_[(size_t)p]), std::get<1>(points_[(size_t)p]), std::get<2>(points_[(size_t)p]), &uu, &vv, &ww);
+                u->coeffRef(p) = u_old->coeffRef(p) = uu;
+                v->coeffRef(p) = v_old->coeffRef(p) = vv;
+                w->coeffRef(p) = w_old->coeffRef(p) = ww;
+            }
+        return;
+    }
     if (flowType.compare("kovasznay") != 0) return;
     for (const Boundary &b : boundaries_)
         for (int p : b.bcPoints) {
@@ -86,7 +129,7 @@ void FractionalStepGrid::set_uv_bound()
         }
 }
 
-// fractionalStepGrid.cpp:60-100: one stencil row for EVERY point (which: 0 d/dx, 1 d/dy, 2 Laplacian)
+// fractionalStepGrid.cpp:60-100: one stencil row for EVERY point (which: 0 d/dx, 1 d/dy, 2 Laplacian, 3 d/dz)
 Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 {
     const int n = laplaceMatSize_;
@@ -99,7 +142,7 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
         vector<int> nbr;
         vector<double> w;
         const int ss = stencilSizeFor(properties_.polyDeg, dim_);
-        if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, {which == 0 ? 1 : (which == 1 ? 2 : 0)}, nbr, w)) {
+        if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, {which == 0 ? 1 : (which == 1 ? 2 : (which == 3 ? 3 : 0))}, nbr, w)) {
             vector<Triplet> trip;
             trip.reserve((size_t)n * (size_t)ss);
             for (int i = 0; i < n; ++i)
@@ -117,7 +160,7 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
             const int i = next.fetch_add(8);
             if (i >= n) break;
             for (int k = i; k < std::min(n, i + 8); ++k) {
-                auto w = which == 0 ? derivx_weights(k) : (which == 1 ? derivy_weights(k) : laplaceWeights(k));
+                auto w = which == 0 ? derivx_weights(k) : (which == 1 ? derivy_weights(k) : (which == 3 ? derivz_weights(k) : laplaceWeights(k)));
                 W[(size_t)k] = w.first.host();
                 NB[(size_t)k] = std::move(w.second);
             }
@@ -138,6 +181,12 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 void FractionalStepGrid::build_derivX_mat() { delete derivXMat_; derivXMat_ = build_op(0); }
 void FractionalStepGrid::build_derivY_mat() { delete derivYMat_; derivYMat_ = build_op(1); }
 void FractionalStepGrid::build_uv_laplace_mat() { delete uvLaplaceMat_; uvLaplaceMat_ = build_op(2); }
+void FractionalStepGrid::build_derivZ_mat()
+{
+    if (dim_ < 3) throw std::invalid_argument("build_derivZ_mat: 3-D grids only");
+    delete derivZMat_;
+    derivZMat_ = build_op(3);
+}
 
 void FractionalStepGrid::fs_device()
 {
@@ -149,19 +198,39 @@ void FractionalStepGrid::fs_device()
     for (int i = 0; i < n; ++i) { nx[(size_t)i] = std::get<0>(normalVecs_[(size_t)i]); ny[(size_t)i] = std::get<1>(normalVecs_[(size_t)i]); }
     std::vector<int> bpts;
     for (const Boundary &b : boundaries_) bpts.insert(bpts.end(), b.bcPoints.begin(), b.bcPoints.end());
+    if (dim_ >= 3) {
+        if (!derivZMat_) throw std::runtime_error("FractionalStepGrid: build_derivZ_mat first (3-D)");
+        std::vector<double> nz((size_t)n);
+        for (int i = 0; i < n; ++i) nz[(size_t)i] = std::get<2>(normalVecs_[(size_t)i]);
+        SparseRowMajor *ops[4] = {derivXMat_, derivYMat_, derivZMat_, uvLaplaceMat_};
+        const int *rp[4], *cl[4];
+        const double *vl[4];
+        for (int k = 0; k < 4; ++k) { rp[k] = ops[k]->outerIndexPtr(); cl[k] = ops[k]->innerIndexPtr(); vl[k] = ops[k]->valuePtr(); }
+        dev_check(mmg_fracstep_create_3d(&fs_, device(), n, rp, cl, vl, nx.data(), ny.data(), nz.data(), bpts.data(), (int)bpts.size()),
+                  "mmg_fracstep_create_3d");
+    } else
     dev_check(mmg_fracstep_create(&fs_, device(), n, derivXMat_->outerIndexPtr(), derivXMat_->innerIndexPtr(),
                                   derivXMat_->valuePtr(), derivYMat_->outerIndexPtr(), derivYMat_->innerIndexPtr(),
                                   derivYMat_->valuePtr(), uvLaplaceMat_->outerIndexPtr(), uvLaplaceMat_->innerIndexPtr(),
                                   uvLaplaceMat_->valuePtr(), nx.data(), ny.data(), bpts.data(), (int)bpts.size()),
               "mmg_fracstep_create");
+    // Grid::push_inhomog_to_rhs on the device needs the interior-row entries in Neumann columns and the diagonal
+    if (implicitFlag_ && neumann_boundary_coeffs_ && neumann_boundary_coeffs_->rows() >= n) {
+        std::vector<double> dg((size_t)n);
+        for (int i = 0; i < n; ++i) dg[(size_t)i] = diags.coeff(i);
+        dev_check(mmg_level_set_neumann_coupling(device(), neumann_boundary_coeffs_->outerIndexPtr(),
+                                                 neumann_boundary_coeffs_->innerIndexPtr(), neumann_boundary_coeffs_->valuePtr(),
+                                                 dg.data()),
+                  "mmg_level_set_neumann_coupling");
+    }
     attach_fs_mirrors();
 }
 
 void FractionalStepGrid::attach_fs_mirrors()
 {
     mmg_fracstep *h = fs_;
-    VectorXd *vecs[4] = {u, v, u_hat, v_hat};
-    for (int k = 0; k < 4; ++k) {
+    VectorXd *vecs[6] = {u, v, u_hat, v_hat, w, w_hat};
+    for (int k = 0; k < (dim_ >= 3 ? 6 : 4); ++k) {
         vecs[k]->attach([h, k](double *dst, size_t cnt) { dev_check(mmg_fracstep_get(h, k, dst, (int)cnt), "mmg_fracstep_get"); });
         vecs[k]->host_mut();  // nothing uploaded yet
     }
@@ -170,8 +239,8 @@ void FractionalStepGrid::attach_fs_mirrors()
 void FractionalStepGrid::push_uv()
 {
     fs_device();
-    VectorXd *vecs[4] = {u, v, u_hat, v_hat};
-    for (int k = 0; k < 4; ++k)
+    VectorXd *vecs[6] = {u, v, u_hat, v_hat, w, w_hat};
+    for (int k = 0; k < (dim_ >= 3 ? 6 : 4); ++k)
         if (vecs[k]->host_newer()) {
             dev_check(mmg_fracstep_set(fs_, k, vecs[k]->data(), (int)vecs[k]->rows()), "mmg_fracstep_set");
             vecs[k]->mark_uploaded();
@@ -186,7 +255,13 @@ void FractionalStepGrid::calc_u_hat()
     dev_check(mmg_fracstep_calc_hat(fs_, dt, mu, rho), "mmg_fracstep_calc_hat");
     u_hat->mark_device_newer();
     v_hat->mark_device_newer();
+    if (dim_ >= 3) w_hat->mark_device_newer();
     hat_done_ = true;
+}
+void FractionalStepGrid::calc_w_hat()
+{
+    if (dim_ < 3) throw std::invalid_argument("calc_w_hat: 3-D grids only");
+    if (!w_hat->device_newer()) calc_u_hat();  // one device call produces all three
 }
 void FractionalStepGrid::calc_v_hat()
 {
@@ -210,7 +285,46 @@ void FractionalStepGrid::correct_u()
     dev_check(mmg_fracstep_correct(fs_, dt, rho), "mmg_fracstep_correct");
     u->mark_device_newer();
     v->mark_device_newer();
+    if (dim_ >= 3) w->mark_device_newer();
     hat_done_ = true;  // reuse the flag: correct_v() right after is already done
+}
+void FractionalStepGrid::correct_w()
+{
+    if (dim_ < 3) throw std::invalid_argument("correct_w: 3-D grids only");
+    if (!w->device_newer()) correct_u();  // one device call corrects all three
+}
+
+void FractionalStepGrid::upload_bound_values()
+{
+    // what set_uv_bound() writes into u, v (, w) at the boundary points, as per-boundary-point arrays
+    set_uv_bound();
+    push_uv();
+    std::vector<int> bpts;
+    for (const Boundary &b : boundaries_) bpts.insert(bpts.end(), b.bcPoints.begin(), b.bcPoints.end());
+    VectorXd *comp[3] = {u, v, w};
+    for (int c = 0; c < (dim_ >= 3 ? 3 : 2); ++c) {
+        std::vector<double> vals(bpts.size());
+        for (size_t k = 0; k < bpts.size(); ++k) vals[k] = comp[c]->coeff(bpts[k]);
+        dev_check(mmg_fracstep_set_bound_values(fs_, c, vals.data(), (int)vals.size()), "mmg_fracstep_set_bound_values");
+    }
+}
+
+double FractionalStepGrid::time_step(Multigrid *mg, int max_cycles, int *cycles)
+{
+    if (!mg || mg->grids_.empty() || mg->grids_.back().second != this)
+        throw std::invalid_argument("time_step: the multigrid's finest grid must be this grid");
+    fs_device();
+    if (!bound_uploaded_) { upload_bound_values(); bound_uploaded_ = true; }
+    push_uv();
+    sync_to_device();
+    double r = 0.0;
+    dev_check(mmg_fracstep_step(fs_, mg->device_hierarchy(), dt, mu, rho, ppe_conv_res, max_cycles, cycles, &r), "mmg_fracstep_step");
+    for (VectorXd *x : {u, v, u_hat, v_hat}) x->mark_device_newer();
+    if (dim_ >= 3) { w->mark_device_newer(); w_hat->mark_device_newer(); }
+    mg->mark_device_state();
+    mark_values_on_device();
+    mark_source_on_device();
+    return r;
 }
 void FractionalStepGrid::correct_v()
 {

@@ -19,6 +19,9 @@ public:
     std::string flowType;
     VectorXd *u, *v, *u_old, *v_old, *v_hat, *u_hat;
     SparseRowMajor *derivXMat_ = nullptr, *derivYMat_ = nullptr, *uvLaplaceMat_ = nullptr;
+    // 3-D extension (BASELINE configs[4]; the reference class is 2-D): third velocity component and D_z
+    VectorXd *w = nullptr, *w_old = nullptr, *w_hat = nullptr;
+    SparseRowMajor *derivZMat_ = nullptr;
 
     FractionalStepGrid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source);
     ~FractionalStepGrid() override;
@@ -34,13 +37,23 @@ public:
     void correct_v();             // :149-151  (device)
     double fs_residual();         // :152-154  (device)
     void prescribe_soln();        // :26-40
+    // 3-D
+    void build_derivZ_mat();
+    void calc_w_hat();            // (device; produced together with u_hat, v_hat)
+    void correct_w();             // (device)
+    // One time step of run_fracstep_param (FractionalStepSim.cpp:131-147) with the pressure solve by `mg`
+    // (a FractionalStepMultigrid whose finest grid is this one), device-resident (mmg_fracstep_step).
+    // Returns fs_residual(); *cycles = V-cycles taken.
+    double time_step(class Multigrid *mg, int max_cycles, int *cycles);
 
 protected:
     SparseRowMajor *build_op(int which);
     void fs_device();
     void push_uv();               // host u, v -> device when the host copy is newer
     void attach_fs_mirrors();
+    void upload_bound_values();   // set_uv_bound's values per boundary point -> mmg_fracstep_set_bound_values
     mmg_fracstep *fs_ = nullptr;
     bool hat_done_ = false;
+    bool bound_uploaded_ = false;
 };
 #endif

@@ -68,7 +68,7 @@ public:
     // domain decomposition: bcFlags_ == 3 marks a GHOST point (copy of a point owned by
     // another rank): searchable as a stencil neighbour, never relaxed, no matrix row.
     // Owned points come first, ghosts last, grouped by owner.
-    static const int kGhost = 3;
+    static constexpr int kGhost = 3;
     int nOwned_ = -1;            // -1: not a sub-domain
     vector<int> origIndex_;      // global id of every local point (sub-domains) / index before reordering
     vector<int> ghostOwner_;     // owner rank of ghost k (k-th point after the owned ones)

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <thread>
 #include <string>
 #include <vector>
@@ -325,51 +326,111 @@ int mmgh_grid_sor_wrong_args(void *gp)  // error behaviour check: foreign vector
 }
 
 // ---- FractionalStepGrid (FractionalStepSim.cpp:3-49 genFractionalStepGrid) ----------------------
+namespace {
+FractionalStepGrid *gen_fs_grid(int n, const double *xyz, int dim, int polydeg, double dt, double mu, double rho, int ordering,
+                                int tile_points, int coarse)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    GridProperties props = make_props(polydeg, dim, 1.4, 5);
+    const double re = rho / mu;
+    const double lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * PI_REF * PI_REF);
+    Boundary b;
+    b.type = 2;
+    for (int i = 0; i < n; ++i)
+        if (on_box_boundary(pts[(size_t)i], dim)) {
+            b.bcPoints.push_back(i);
+            // 2-D: the Kovasznay pressure data of the reference's driver; 3-D (no reference flow): homogeneous
+            b.values.push_back(dim >= 3 ? 0.0 : 0.5 * std::exp(2 * lambda * std::get<0>(pts[(size_t)i])));
+        }
+    FractionalStepGrid *g = new FractionalStepGrid(pts, std::vector<Boundary>(1, b), props, mmgh::Vec((size_t)n + 1));
+    g->dim_ = dim;
+    g->mu = mu;
+    g->rho = rho;
+    g->dt = dt;
+    g->ppe_conv_res = 1e-10;
+    g->implicitFlag_ = true;
+    g->flowType = dim >= 3 ? "taylor_green_3d" : "kovasznay";
+    g->setBCFlag(0, "neumann", b.values);
+    g->build_normal_vecs("", "square");
+    order_points(g, ordering, tile_points);
+    g->build_deriv_normal_bound();
+    g->build_laplacian();
+    g->modify_coeff_neumann(coarse ? "coarse" : "fine");
+    g->build_derivX_mat();
+    g->build_derivY_mat();
+    if (dim >= 3) g->build_derivZ_mat();
+    g->build_uv_laplace_mat();
+    g->push_inhomog_to_rhs();
+    return g;
+}
+}  // namespace
+
 void *mmgh_fs_create_square(int n, const double *xyz, int polydeg, double dt, double mu, double rho, int ordering,
                             int tile_points, int coarse)
 {
     FractionalStepGrid *g = nullptr;
-    const int rc = guard([&]() {
-        std::vector<Point> pts = to_points(xyz, n);
-        GridProperties props = make_props(polydeg, 2, 1.4, 5);
-        const double re = rho / mu;
-        const double lambda = 0.5 * re - std::sqrt(0.25 * re * re + 4 * PI_REF * PI_REF);
-        Boundary b;
-        b.type = 2;
-        for (int i = 0; i < n; ++i)
-            if (on_box_boundary(pts[(size_t)i], 2)) { b.bcPoints.push_back(i); b.values.push_back(0.5 * std::exp(2 * lambda * std::get<0>(pts[(size_t)i]))); }
-        g = new FractionalStepGrid(pts, std::vector<Boundary>(1, b), props, mmgh::Vec((size_t)n + 1));
-        g->mu = mu;
-        g->rho = rho;
-        g->dt = dt;
-        g->ppe_conv_res = 1e-10;
-        g->implicitFlag_ = true;
-        g->flowType = "kovasznay";
-        g->setBCFlag(0, "neumann", b.values);
-        g->build_normal_vecs("", "square");
-        order_points(g, ordering, tile_points);
-        g->build_deriv_normal_bound();
-        g->build_laplacian();
-        g->modify_coeff_neumann(coarse ? "coarse" : "fine");
-        g->build_derivX_mat();
-        g->build_derivY_mat();
-        g->build_uv_laplace_mat();
-        g->push_inhomog_to_rhs();
-    });
-    if (rc) { delete g; return nullptr; }
+    if (guard([&]() { g = gen_fs_grid(n, xyz, 2, polydeg, dt, mu, rho, ordering, tile_points, coarse); })) { delete g; return nullptr; }
     return g;
 }
-// which: 0 D_x, 1 D_y, 2 velocity Laplacian
+void *mmgh_fs_create_box(int n, const double *xyz, int dim, int polydeg, double dt, double mu, double rho, int ordering,
+                         int tile_points, int coarse)
+{
+    FractionalStepGrid *g = nullptr;
+    if (guard([&]() { g = gen_fs_grid(n, xyz, dim, polydeg, dt, mu, rho, ordering, tile_points, coarse); })) { delete g; return nullptr; }
+    return g;
+}
+// run_fracstep_param's hierarchy (FractionalStepSim.cpp:115-121): a FractionalStepMultigrid over
+// FractionalStepGrids, every level but the finest built "coarse"
+void *mmgh_mg_create_fs(int nlevels, const int *npts, const double *xyz, const int *polydeg, int dim, double dt, double mu,
+                        double rho, int ordering, int tile_points)
+{
+    FractionalStepMultigrid *mg = nullptr;
+    const int rc = guard([&]() {
+        mg = new FractionalStepMultigrid();
+        size_t off = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            mg->addGrid(gen_fs_grid(npts[l], xyz + 3 * off, dim, polydeg[l], dt, mu, rho, ordering, tile_points, l != nlevels - 1));
+            off += (size_t)npts[l];
+        }
+        mg->buildMatrices();
+    });
+    if (rc) { delete mg; return nullptr; }
+    return mg;
+}
+// one device-resident time step on the hierarchy's finest grid; returns fs_residual through *resid
+int mmgh_mg_fs_step(void *h, int max_cycles, int *cycles, double *resid)
+{
+    return guard([&]() {
+        Multigrid *mg = static_cast<Multigrid *>(h);
+        FractionalStepGrid *g = dynamic_cast<FractionalStepGrid *>(mg->grids_.back().second);
+        if (!g) throw std::invalid_argument("fs_step: the finest grid is no FractionalStepGrid");
+        *resid = g->time_step(mg, max_cycles, cycles);
+    });
+}
+// CSR + diagonal behind Grid::push_inhomog_to_rhs (neumann_boundary_coeffs_, diags)
+int mmgh_grid_coupling_nnz(void *gp) { return static_cast<Grid *>(gp)->neumann_boundary_coeffs_->nonZeros(); }
+void mmgh_grid_coupling_get(void *gp, int *rowptr, int *col, double *val, double *diag)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    mmgh::Sparse *m = g->neumann_boundary_coeffs_;
+    std::memcpy(rowptr, m->outerIndexPtr(), sizeof(int) * ((size_t)m->rows() + 1));
+    std::memcpy(col, m->innerIndexPtr(), sizeof(int) * (size_t)m->nonZeros());
+    std::memcpy(val, m->valuePtr(), sizeof(double) * (size_t)m->nonZeros());
+    for (int i = 0; i < g->laplaceMatSize_; ++i) diag[i] = g->diags.coeff(i);
+}
+// which: 0 D_x, 1 D_y, 2 velocity Laplacian, 3 D_z (3-D)
+static mmgh::Sparse *fs_op(FractionalStepGrid *g, int which)
+{
+    return which == 0 ? g->derivXMat_ : (which == 1 ? g->derivYMat_ : (which == 3 ? g->derivZMat_ : g->uvLaplaceMat_));
+}
 int mmgh_fs_op_nnz(void *gp, int which)
 {
-    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
-    mmgh::Sparse *m = which == 0 ? g->derivXMat_ : (which == 1 ? g->derivYMat_ : g->uvLaplaceMat_);
-    return m->nonZeros();
+    mmgh::Sparse *m = fs_op(static_cast<FractionalStepGrid *>(gp), which);
+    return m ? m->nonZeros() : -1;
 }
 void mmgh_fs_op_get(void *gp, int which, int *rowptr, int *col, double *val)
 {
-    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
-    mmgh::Sparse *m = which == 0 ? g->derivXMat_ : (which == 1 ? g->derivYMat_ : g->uvLaplaceMat_);
+    mmgh::Sparse *m = fs_op(static_cast<FractionalStepGrid *>(gp), which);
     std::memcpy(rowptr, m->outerIndexPtr(), sizeof(int) * ((size_t)m->rows() + 1));
     std::memcpy(col, m->innerIndexPtr(), sizeof(int) * (size_t)m->nonZeros());
     std::memcpy(val, m->valuePtr(), sizeof(double) * (size_t)m->nonZeros());
@@ -379,8 +440,17 @@ void mmgh_fs_get_normals(void *gp, double *nx, double *ny)
     FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
     for (size_t i = 0; i < g->normalVecs_.size(); ++i) { nx[i] = std::get<0>(g->normalVecs_[i]); ny[i] = std::get<1>(g->normalVecs_[i]); }
 }
-// which: 0 u, 1 v, 2 u_hat, 3 v_hat
-static mmgh::Vec *fs_vec(FractionalStepGrid *g, int which) { return which == 0 ? g->u : (which == 1 ? g->v : (which == 2 ? g->u_hat : g->v_hat)); }
+void mmgh_fs_get_normal_z(void *gp, double *nz)
+{
+    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
+    for (size_t i = 0; i < g->normalVecs_.size(); ++i) nz[i] = std::get<2>(g->normalVecs_[i]);
+}
+// which: 0 u, 1 v, 2 u_hat, 3 v_hat, 4 w, 5 w_hat
+static mmgh::Vec *fs_vec(FractionalStepGrid *g, int which)
+{
+    mmgh::Vec *all[6] = {g->u, g->v, g->u_hat, g->v_hat, g->w, g->w_hat};
+    return all[which < 0 || which > 5 ? 0 : which];
+}
 int mmgh_fs_get_vec(void *gp, int which, double *w)
 {
     return guard([&]() { mmgh::Vec *x = fs_vec(static_cast<FractionalStepGrid *>(gp), which); std::memcpy(w, x->data(), sizeof(double) * (size_t)x->rows()); });
@@ -392,10 +462,16 @@ void mmgh_fs_set_vec(void *gp, int which, const double *w)
 }
 void mmgh_fs_prescribe_soln(void *gp) { static_cast<FractionalStepGrid *>(gp)->prescribe_soln(); }
 void mmgh_fs_set_uv_bound(void *gp) { static_cast<FractionalStepGrid *>(gp)->set_uv_bound(); }
-int mmgh_fs_calc_hat(void *gp) { return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->calc_u_hat(); g->calc_v_hat(); }); }
+int mmgh_fs_calc_hat(void *gp)
+{
+    return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->calc_u_hat(); g->calc_v_hat(); if (g->dim_ >= 3) g->calc_w_hat(); });
+}
 int mmgh_fs_set_ppe_source(void *gp) { return guard([&]() { static_cast<FractionalStepGrid *>(gp)->set_ppe_source(); }); }
 int mmgh_fs_push_inhomog(void *gp) { return guard([&]() { static_cast<FractionalStepGrid *>(gp)->push_inhomog_to_rhs(); }); }
-int mmgh_fs_correct(void *gp) { return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->correct_u(); g->correct_v(); }); }
+int mmgh_fs_correct(void *gp)
+{
+    return guard([&]() { auto *g = static_cast<FractionalStepGrid *>(gp); g->correct_u(); g->correct_v(); if (g->dim_ >= 3) g->correct_w(); });
+}
 int mmgh_fs_residual(void *gp, double *r) { return guard([&]() { *r = static_cast<FractionalStepGrid *>(gp)->fs_residual(); }); }
 
 // ---- domain decomposition ----------------------------------------------------------------

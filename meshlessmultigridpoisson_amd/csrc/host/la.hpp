@@ -67,6 +67,7 @@ public:
     void attach(std::function<void(double *, size_t)> pull_fn) { pull_fn_ = std::move(pull_fn); }
     void detach() { pull(); pull_fn_ = nullptr; dev_newer_ = false; }
     bool host_newer() const { return host_newer_; }
+    bool device_newer() const { return dev_newer_; }
     void mark_uploaded() { host_newer_ = false; }
     void mark_device_newer() { dev_newer_ = true; host_newer_ = false; }
 

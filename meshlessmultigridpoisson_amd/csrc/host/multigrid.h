@@ -46,6 +46,10 @@ public:
     // registers every level's ghost exchange with the device -- the lists were worked out at extraction, from the
     // global hierarchy every rank holds, without communication.  per_phase: exact mode (mmg_level_set_exchange_mode).
     void setup_exchange(bool per_phase = false);
+    // the device-side hierarchy (created on first use), with every grid's host-side writes uploaded; after a
+    // device-resident operation on it (FractionalStepGrid::time_step) call mark_device_state()
+    mmg_hierarchy *device_hierarchy() { ensure_device(); sync_all(); return devH_; }
+    void mark_device_state() { mark_all(); }
 
 protected:
     void ensure_device();

@@ -106,7 +106,33 @@ def oracle_of_fracstep(g):
     from oracle import oracle_c as oc
     nx, ny = g.normals()
     _bt, _bp, bpts, _bv = g.boundaries()
+    if getattr(g, "dim", 2) >= 3:
+        return oc.FracStep3(g.sizes()["n"], g.op(0), g.op(1), g.op(3), g.op(2), nx, ny, g.normal_z(), bpts)
     return oc.FracStep(g.sizes()["n"], g.op(0), g.op(1), g.op(2), nx, ny, bpts)
+
+
+def oracle_fracstep_time_step(om, ofs, g_arrays, dt, mu, rho, tol, max_cycles):
+    """One time step of run_fracstep_param (FractionalStepSim.cpp:131-147) with oracle objects: om the oracle
+    Multigrid (frac_step), ofs the oracle FracStep(3) of its finest grid, g_arrays = dict(bpts, bvals (list of per-
+    component boundary value arrays), coupling=((rp, col, val), diag), bcflags).  Returns (fs_residual, cycles)."""
+    from oracle import oracle_c as oc
+    fine = om.levels[-1]
+    n = ofs.n
+    comps = [ofs.u, ofs.v] + ([ofs.w] if hasattr(ofs, "w") else [])
+    for c, vals in zip(comps, g_arrays["bvals"]):          # set_uv_bound
+        c[g_arrays["bpts"]] = vals
+    ofs.calc_hat(dt, mu, rho)
+    ofs.set_ppe_source(fine.b, dt, rho)
+    oc.push_inhomog(n, g_arrays["coupling"][0], g_arrays["coupling"][1], g_arrays["bcflags"], fine.b)
+    cycles = 0
+    while om.residual() >= tol and cycles < max_cycles:
+        om.vcycle()
+        fine.bound_eval_neumann()
+        cycles += 1
+    ofs.correct(fine.x[:n], dt, rho)
+    for c, vals in zip(comps, g_arrays["bvals"]):
+        c[g_arrays["bpts"]] = vals
+    return ofs.residual(), cycles
 
 
 # ---- CPU interpreter of the packed plan (tests/support/plan_emulate.cpp) ------------

@@ -1,0 +1,116 @@
+"""GPU tests of the fractional-step path beyond the single 2-D grid: the device-resident time step
+(FractionalStepSim.cpp:131-147: predictor, PPE source, push_inhomog_to_rhs, `while (mg.residual() >= tol)
+{ mg.vCycle(); bound_eval_neumann(); }`, corrector) in 2-D as the reference has it, and its 3-D extension
+(third velocity component, D_z, n_z -- BASELINE configs[4]; no reference counterpart, oracle = the same
+statements with the third component added, oracle/mmg_oracle.c: orc_fs_*3).
+Tolerances: single operations 1e-12 relative; after a time step (V-cycles included) 1e-9 relative."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host():
+    from meshlessmultigridpoisson_amd import _capi, _host
+    assert _capi.device_count() >= 1, "no HIP device visible: libmmgp has no CPU fallback"
+    return _host
+
+
+def _ncomp(g):
+    return 3 if g.dim >= 3 else 2
+
+
+def _vecs(g):
+    return [g.vec(0), g.vec(1)] + ([g.vec(4)] if g.dim >= 3 else [])
+
+
+def test_fracstep_3d_grid_ops_match_oracle(host):
+    """Predictor, PPE source, push_inhomog_to_rhs and corrector of a 3-D FractionalStepGrid on the device vs the
+    oracle's 3-D statements on the operators the host class built (D_x, D_y, D_z, Laplacian: K = 25 stencils of
+    a jittered 11^3 cloud, Neumann pressure with implicit elimination)."""
+    pts = host.box_cloud(11, 3, seed=5)
+    g = host.FracStepGrid.create(pts, polydeg=2, dt=1e-3, mu=0.05, rho=1.0, dim=3, ordering=host.ORDER_MC, tile_points=128)
+    o = H.oracle_of_fracstep(g)
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    rng = np.random.default_rng(0)
+    for k in (0, 1, 4):
+        g.set_vec(k, g.vec(k) + 1e-3 * rng.standard_normal(n))
+    g.set_uv_bound()
+    o.u[:], o.v[:], o.w[:] = g.vec(0), g.vec(1), g.vec(4)
+    g.calc_hat()
+    o.calc_hat(g.dt, g.mu, g.rho)
+    for k, want in ((2, o.u_hat), (3, o.v_hat), (5, o.w_hat)):
+        assert H.rel_err(g.vec(k), want) < 1e-12, k
+    src_o = g.source().copy()
+    g.set_ppe_source()
+    o.set_ppe_source(src_o, g.dt, g.rho)
+    assert np.abs(g.source() - src_o).max() <= 1e-11 * np.abs(src_o).max()
+    # push_inhomog_to_rhs on the DEVICE (mmg_level_push_inhomog_to_rhs) vs grid.cpp:664-685 restated
+    from meshlessmultigridpoisson_amd import _capi
+    from oracle import oracle_c as oc
+    (rp, col, val), diag = g.coupling()
+    _xyz, flags = g.points()
+    sz = g.sizes()
+    lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
+    f = _capi.lib().mmg_level_set_neumann_coupling
+    import ctypes as C
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _capi.check(f(lv.h, rp.ctypes.data_as(C.POINTER(C.c_int)), col.ctypes.data_as(C.POINTER(C.c_int)),
+                  val.ctypes.data_as(C.POINTER(C.c_double)), diag.ctypes.data_as(C.POINTER(C.c_double))))
+    p2 = _capi.lib().mmg_level_push_inhomog_to_rhs
+    p2.argtypes = [C.c_void_p]
+    before = lv.get_rhs()
+    _capi.check(p2(lv.h))
+    want = before.copy()
+    oc.push_inhomog(n, (rp, col, val), diag, flags, want)
+    assert np.abs(want - before).max() > 0            # the coupling is not empty on this cloud
+    assert np.abs(lv.get_rhs() - want).max() <= 1e-12 * np.abs(want).max()
+    # corrector with a smoothed pressure
+    lvl = H.oracle_level(g.level_arrays())
+    for _ in range(2):
+        g.sor()
+        lvl.sor()
+    assert H.rel_err(g.values(), lvl.x) < 1e-12
+    g.correct()
+    o.correct(lvl.x[:n], g.dt, g.rho)
+    for k, want in ((0, o.u), (1, o.v), (4, o.w)):
+        assert H.rel_err(g.vec(k), want) < 1e-12, k
+    assert abs(g.fs_residual() - o.residual()) <= 1e-12 * o.residual()
+
+
+@pytest.mark.parametrize("dim,sides,deg", [(2, [15, 29], 3), (3, [7, 13], 2)])
+def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg):
+    """Two time steps of run_fracstep_param's loop, device-resident (mmg_fracstep_step through
+    FractionalStepGrid::time_step), on a two-level FractionalStepMultigrid vs the same loop over oracle objects.
+    The pressure loop is capped at 6 V-cycles per step (both sides reach the cap: 1e-10 is far below what six
+    cycles give), so the comparison covers set_uv_bound, predictor, source, push_inhomog_to_rhs, six V-cycles
+    with bound_eval_neumann after each, the corrector and fs_residual."""
+    cloud = (lambda n, s: host.square_cloud(n, seed=s)) if dim == 2 else (lambda n, s: host.box_cloud(n, 3, seed=s))
+    clouds = [cloud(n, 12345 + i) for i, n in enumerate(sides)]
+    mg = host.FracStepMultigrid(clouds, [deg] * len(sides), dim=dim, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC,
+                                tile_points=128)
+    g = mg.fs_grid()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    g.set_uv_bound()
+    om = H.oracle_of_multigrid(mg)
+    assert om.frac_step
+    ofs = H.oracle_of_fracstep(g)
+    comps = [ofs.u, ofs.v] + ([ofs.w] if dim == 3 else [])
+    for c, vals in zip(comps, _vecs(g)):
+        c[:] = vals
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[c[bpts].copy() for c in comps], coupling=g.coupling(), bcflags=flags)
+    for step in range(2):
+        r_dev, nc_dev = mg.step(max_cycles=6)
+        r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6)
+        assert nc_dev == nc_orc == 6, (step, nc_dev, nc_orc)
+        for got, want in zip(_vecs(g), comps):
+            assert H.rel_err(got, want) < 1e-9, step
+        assert H.rel_err(g.values()[:n], om.levels[-1].x[:n]) < 1e-9, step
+        assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)

@@ -87,3 +87,47 @@ def test_hybrid_schedule_equals_sequential_for_one_part():
     c.sor_hybrid((np.arange(la["n"]) * 2 // la["n"]).astype(np.int32), 2, 3)
     n = la["n"]
     assert not np.array_equal(a.x, c.x) and np.abs(a.x[:n] - c.x[:n]).max() < 0.5 * np.abs(a.x[:n]).max()
+
+
+def test_oracle_3d_fracstep_statements_against_numpy():
+    """The 3-D extension of the oracle (orc_fs_*3) and orc_push_inhomog (grid.cpp:664-685), checked against the
+    same statements written with scipy / numpy on random operators -- pins the C restatement independently of
+    the product."""
+    import scipy.sparse as sp
+    from oracle import oracle_c as oc
+    rng = np.random.default_rng(4)
+    n = 60
+    mats = [sp.random(n, n, density=0.2, random_state=int(s), format="csr") for s in (1, 2, 3, 4)]
+    csr = [(m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy()) for m in mats]
+    nx, ny, nz = rng.standard_normal((3, n))
+    bpts = np.arange(0, n, 7, dtype=np.int32)
+    o = oc.FracStep3(n, csr[0], csr[1], csr[2], csr[3], nx, ny, nz, bpts)
+    o.u[:], o.v[:], o.w[:] = rng.standard_normal((3, n))
+    dt, mu, rho = 1e-2, 0.3, 1.7
+    o.calc_hat(dt, mu, rho)
+    dx, dy, dz, lap = mats
+    for c, h in ((o.u, o.u_hat), (o.v, o.v_hat), (o.w, o.w_hat)):
+        want = c + dt * (-(o.u * (dx @ c) + o.v * (dy @ c) + o.w * (dz @ c)) + mu / rho * (lap @ c))
+        assert np.allclose(h, want, rtol=1e-13, atol=1e-14)
+    src = np.zeros(n + 1)
+    o.set_ppe_source(src, dt, rho)
+    want = rho / dt * (dx @ o.u_hat + dy @ o.v_hat + dz @ o.w_hat)
+    g = -rho / dt * np.stack([o.u - o.u_hat, o.v - o.v_hat, o.w - o.w_hat])
+    want[bpts] = (nx * g[0] + ny * g[1] + nz * g[2])[bpts]
+    assert np.allclose(src[:n], want, rtol=1e-12, atol=1e-12)
+    p = rng.standard_normal(n)
+    o.correct(p, dt, rho)
+    assert np.allclose(o.w, o.w_hat - dt / rho * (dz @ p), rtol=1e-13, atol=1e-14)
+    # push_inhomog: b_i -= sum_j A_ij * b_j / a_jj over interior rows i
+    flags = rng.integers(0, 3, n).astype(np.int32)
+    diag = 1.0 + rng.random(n)
+    b = rng.standard_normal(n + 1)
+    want = b.copy()
+    C = mats[0]
+    for i in range(n):
+        if flags[i] == 0:
+            for q in range(C.indptr[i], C.indptr[i + 1]):
+                want[i] -= C.data[q] * b[C.indices[q]] / diag[C.indices[q]]
+    oc.push_inhomog(n, csr[0], diag, flags, b)
+    assert np.allclose(b, want, rtol=1e-14, atol=1e-15)
+
