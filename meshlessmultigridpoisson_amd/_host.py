@@ -83,14 +83,15 @@ def lib():
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_fs_create_square.restype = vp
         L.mmgh_fs_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
-        L.mmgh_fs_create_box.restype = vp
-        L.mmgh_fs_create_box.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
-        L.mmgh_mg_create_fs.restype = vp
-        L.mmgh_mg_create_fs.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
-        L.mmgh_mg_fs_step.argtypes = [vp, C.c_int, _ip, _dp]
-        L.mmgh_grid_coupling_nnz.argtypes = [vp]
-        L.mmgh_grid_coupling_get.argtypes = [vp, _ip, _ip, _dp, _dp]
-        L.mmgh_fs_get_normal_z.argtypes = [vp, _dp]
+        if hasattr(L, "mmgh_fs_create_box"):  # (absent from older builds loaded through MMGP_LIBDIR for A/B runs)
+            L.mmgh_fs_create_box.restype = vp
+            L.mmgh_fs_create_box.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+            L.mmgh_mg_create_fs.restype = vp
+            L.mmgh_mg_create_fs.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+            L.mmgh_mg_fs_step.argtypes = [vp, C.c_int, _ip, _dp]
+            L.mmgh_grid_coupling_nnz.argtypes = [vp]
+            L.mmgh_grid_coupling_get.argtypes = [vp, _ip, _ip, _dp, _dp]
+            L.mmgh_fs_get_normal_z.argtypes = [vp, _dp]
         L.mmgh_fs_op_nnz.argtypes = [vp, C.c_int]
         L.mmgh_fs_op_get.argtypes = [vp, C.c_int, _ip, _ip, _dp]
         L.mmgh_fs_get_normals.argtypes = [vp, _dp, _dp]

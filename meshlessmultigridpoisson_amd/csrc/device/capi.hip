@@ -967,15 +967,16 @@ struct LevelLayout {
 LevelLayout level_layout(long long n_points, double avg_row_len)
 {
     if (avg_row_len >= 44.0) {  // 3-D stencils (K = 50): 8 tile colours, ~23 dependency levels per tile
-        if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows
-        if (n_points <= 3000000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217 us)
+        if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows, 4 entries per lane
+        if (n_points <= 3000000) return {true, 512, 8, 3};    // bandwidth starts to matter: 7 of 7 entry slots used, rounds of 3 x 8 rows
         return {false, 0, 0, 1};
     }
     if (avg_row_len <= 30.0) {  // 2-D K = 25 (the coarse levels of the reference's hierarchies)
         if (n_points <= 600000) return {true, 256, 8, 3};
         return {false, 0, 0, 1};
     }
-    if (n_points <= 300000) return {true, 256, 8, 4};          // 2-D K = 37 ... 70
+    if (n_points <= 300000) return {true, 256, 8, 2};          // 2-D K = 37 ... 70, small: short chains
+    if (n_points <= 1500000) return {true, 512, 8, 3};         // 2-D K = 37: 5 entries per lane (36 of 40 slots), full rounds
     return {false, 0, 0, 1};
 }
 }  // namespace
@@ -1102,8 +1103,8 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
             waves = ll.dense ? ll.waves : 1;
             if (ll.dense && d->lanes_per_row <= 0) dd.lanes_per_row = ll.lanes;
         }
-        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8))
-            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4, 6 or 8");
+        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6))
+            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4 or 6");
         const std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;

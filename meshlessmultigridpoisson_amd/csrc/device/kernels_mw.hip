@@ -37,38 +37,58 @@ namespace {
 
 template <int P>
 struct DenseRegs {
-    double2 v[P / 2];  // entries 2h, 2h+1 of the lane
-    uint2 s[P / 4];    // 16-bit LDS slots, four per word
-    uint4 info;        // RowInfo of the lane's row: gid | self, flags | 1 / diag
-    double diag;       // RESID only
+    static constexpr int kPairs = P / 2;
+    static constexpr int kSlotWords = P <= 4 ? 2 : (P <= 6 ? 3 : 4);  // dwords per lane: dense_slot_bytes(P) / 4
+    double2 v[kPairs > 0 ? kPairs : 1];  // entries 2h, 2h+1 of the lane
+    double vlast;                        // odd P: the last entry
+    unsigned s[kSlotWords];              // 16-bit LDS slots, two per dword
+    uint4 info;                          // RowInfo of the lane's row: gid | self, flags | 1 / diag
+    double diag;                         // RESID only
 };
 
 template <int L, int P>
-struct DenseShape {
+struct DenseShape {  // plan.hpp: dense_off_* / dense_group_bytes
     static constexpr int G = 64 / L;
     static constexpr int kOffDiag = 16 * G;
-    static constexpr int kOffVal = kOffDiag + 8 * G;
+    static constexpr int kOffVal = 24 * G;
     static constexpr int kOffSlot = kOffVal + P * 512;
-    static constexpr int kBytes = kOffSlot + P * 128;  // == dense_group_bytes(L, P)
+    static constexpr int kSlotBytes = 4 * DenseRegs<P>::kSlotWords;
+    static constexpr int kBytes = kOffSlot + kSlotBytes * 64;
 };
 
 template <int L, int P, int MODE>
 __device__ __forceinline__ void issue_dense(const unsigned char *gp, int lane, DenseRegs<P> &r)
 {
     using S = DenseShape<L, P>;
+    using R = DenseRegs<P>;
     r.info = reinterpret_cast<const uint4 *>(gp)[lane / L];
     if (MODE == MODE_RESID) r.diag = reinterpret_cast<const double *>(gp + S::kOffDiag)[lane / L];
 #pragma unroll
-    for (int h = 0; h < P / 2; ++h) r.v[h] = reinterpret_cast<const double2 *>(gp + S::kOffVal + h * 1024)[lane];
-#pragma unroll
-    for (int w = 0; w < P / 4; ++w) r.s[w] = reinterpret_cast<const uint2 *>(gp + S::kOffSlot)[lane * (P / 4) + w];
+    for (int h = 0; h < R::kPairs; ++h) r.v[h] = reinterpret_cast<const double2 *>(gp + S::kOffVal + h * 1024)[lane];
+    if (P & 1) r.vlast = reinterpret_cast<const double *>(gp + S::kOffVal + R::kPairs * 1024)[lane];
+    const unsigned char *sp = gp + S::kOffSlot + lane * S::kSlotBytes;
+    if (R::kSlotWords == 2) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(sp);
+        r.s[0] = w.x;
+        r.s[1] = w.y;
+    } else if (R::kSlotWords == 3) {  // 12 bytes per lane, 4-byte aligned: three dword loads (merged to one dwordx3)
+        const unsigned *w = reinterpret_cast<const unsigned *>(sp);
+        r.s[0] = w[0];
+        r.s[1] = w[1];
+        r.s[2] = w[2];
+    } else {
+        const uint4 w = *reinterpret_cast<const uint4 *>(sp);
+        r.s[0] = w.x;
+        r.s[1] = w.y;
+        r.s[2] = w.z;
+        r.s[3] = w.w;
+    }
 }
 
 template <int P>
-__device__ __forceinline__ unsigned dense_slot(const uint2 (&s)[P / 4], int q)
+__device__ __forceinline__ unsigned dense_slot(const DenseRegs<P> &g, int q)
 {
-    const uint2 &u = s[q >> 2];
-    const unsigned w = (q & 2) ? u.y : u.x;
+    const unsigned w = g.s[q >> 1];
     return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
@@ -156,7 +176,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     auto finish = [&](const DenseRegs<P> &g) {
         double xv[P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) xv[q] = xs[dense_slot<P>(g.s, q)];
+        for (int q = 0; q < P; ++q) xv[q] = xs[dense_slot<P>(g, q)];
         __builtin_amdgcn_sched_barrier(0);  // every gather in flight before the first FMA
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -164,6 +184,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
             acc0 = fma(g.v[h].x, xv[2 * h], acc0);
             acc1 = fma(g.v[h].y, xv[2 * h + 1], acc1);
         }
+        if (P & 1) acc0 = fma(g.vlast, xv[P - 1], acc0);
         const double acc = row_sum<L>(acc0 + acc1);
         const uint32_t gid = g.info.x;
         if (sub == 0 && gid != kNoRow) {
@@ -265,7 +286,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
 #endif
 }
 
-// register sets per wavefront: a group is 4 (P = 4) or 6 (P = 8) load instructions, 14 / 24 registers
+// register sets per wavefront: a group is 4 ... 7 load instructions, 14 ... 26 registers
 template <int P>
 constexpr int kDepthMw = P <= 4 ? 4 : 3;
 
@@ -396,7 +417,6 @@ hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t 
     case 3: return launch_mw_LPN<L, P, 3>(k, a, workers, s, occ);
     case 4: return launch_mw_LPN<L, P, 4>(k, a, workers, s, occ);
     case 6: return launch_mw_LPN<L, P, 6>(k, a, workers, s, occ);
-    case 8: return launch_mw_LPN<L, P, 8>(k, a, workers, s, occ);
     }
     return hipErrorInvalidValue;
 }
@@ -404,8 +424,13 @@ hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t 
 template <int L>
 hipError_t launch_mw_L(MwKernel k, const TileArgs &a, int workers, hipStream_t s, int *occ)
 {
-    if (a.p.max_plen == 4) return launch_mw_LP<L, 4>(k, a, workers, s, occ);
-    if (a.p.max_plen == 8) return launch_mw_LP<L, 8>(k, a, workers, s, occ);
+    switch (a.p.max_plen) {  // plan.hpp: kDensePlens
+    case 3: return launch_mw_LP<L, 3>(k, a, workers, s, occ);
+    case 4: return launch_mw_LP<L, 4>(k, a, workers, s, occ);
+    case 5: return launch_mw_LP<L, 5>(k, a, workers, s, occ);
+    case 7: return launch_mw_LP<L, 7>(k, a, workers, s, occ);
+    case 8: return launch_mw_LP<L, 8>(k, a, workers, s, occ);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -413,7 +438,6 @@ hipError_t launch_mw(MwKernel k, const TileArgs &a, int workers, hipStream_t s, 
 {
     if (!a.p.dense) return hipErrorInvalidValue;
     switch (a.p.L) {
-    case 4: return launch_mw_L<4>(k, a, workers, s, occ);
     case 8: return launch_mw_L<8>(k, a, workers, s, occ);
     case 16: return launch_mw_L<16>(k, a, workers, s, occ);
     }

@@ -46,7 +46,7 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
 
 int dense_lanes(int lanes_per_row, double avg_row_len)
 {
-    if (lanes_per_row == 4 || lanes_per_row == 8 || lanes_per_row == 16) return lanes_per_row;
+    if (lanes_per_row == 8 || lanes_per_row == 16) return lanes_per_row;
     return avg_row_len >= 44.0 ? 16 : 8;
 }
 

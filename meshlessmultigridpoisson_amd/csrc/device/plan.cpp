@@ -190,7 +190,6 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         const size_t GB = dense_group_bytes(L, P);
         tb.blob.assign((size_t)n_rounds * NW * GB, 0);
         uint8_t *B = tb.blob.data();
-        const size_t off_diag = (size_t)16 * G, off_val = off_diag + (size_t)8 * G, off_slot = off_val + (size_t)P * 512;
         for (int r = 0; r < n_rounds; ++r) {
             const auto &rows = by_round[r];
             for (int w = 0; w < NW; ++w) {
@@ -200,21 +199,23 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     RowInfo ri{RowMeta{kNoRow, kNoSlot, 0}, 1.0};
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
                     const double one = 1.0;
-                    std::memcpy(gp + off_diag + (size_t)8 * i, &one, 8);
+                    std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &one, 8);
                 }
-                for (size_t i = 0; i < (size_t)64 * P; ++i) std::memcpy(gp + off_slot + 2 * i, &zero_slot, 2);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (size_t q = 0; q < dense_slot_bytes(P) / 2; ++q)  // padding slots included
+                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_slot, 2);
                 int active = 0;
                 for (size_t idx = (size_t)w, i = 0; idx < rows.size(); idx += NW, ++i) {  // rows w, w+NW, ... of the round
                     const int k = rows[idx];
                     RowInfo ri{meta[k], 1.0 / diag[k]};
                     if (!s.extract_diag) ri.inv_diag = 1.0;
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
-                    std::memcpy(gp + off_diag + (size_t)8 * i, &diag[k], 8);
+                    std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &diag[k], 8);
                     const auto &e = ent[k];
                     for (size_t x = 0; x < e.size(); ++x) {
-                        const size_t q = x / L, lane = i * L + x % L;
-                        std::memcpy(gp + off_val + (q / 2) * 1024 + lane * 16 + (q % 2) * 8, &e[x].val, 8);
-                        std::memcpy(gp + off_slot + (lane * P + q) * 2, &e[x].slot, 2);
+                        const int q = (int)(x / L), lane = (int)(i * L + x % L);
+                        std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
+                        std::memcpy(gp + dense_slot_off(L, P, q, lane), &e[x].slot, 2);
                     }
                     ++active;
                 }
@@ -297,16 +298,18 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     const int n_in = A.cols;
     PlanSpec sd = s;  // dense layout: entries per lane of every group fixed per plan (4 or 8)
     if (s.dense_waves > 0) {
-        if (!(L == 4 || L == 8 || L == 16) || s.exact || s.slot_bits == 12) return "dense layout needs 4, 8 or 16 lanes per row and 16-bit slots";
+        if (!(L == 8 || L == 16) || s.exact || s.slot_bits == 12) return "dense layout needs 8 or 16 lanes per row and 16-bit slots";
         if (s.dense_waves > 16) return "dense layout: at most 16 wavefronts per tile";
         int maxlen = 0;
         for (int64_t k = 0; k < s.n_rows; ++k) {
             if (s.rows[k] < 0 || s.rows[k] >= A.rows) return "row id outside the matrix";
             maxlen = std::max(maxlen, A.rowptr[s.rows[k] + 1] - A.rowptr[s.rows[k]]);
         }
-        const int need = (maxlen + L - 1) / L;  // upper bound (diagonal / multiplier / explicit zeros still inside)
-        if (need > 8) return "rows-too-long-for-dense";
-        sd.dense_plen = need <= 4 ? 4 : 8;
+        // entries per lane: the diagonal (and the multiplier column) leave the row, everything else may stay
+        const int drop = (s.extract_diag ? 1 : 0) + (s.mult_col >= 0 ? 1 : 0);
+        const int need = (std::max(1, maxlen - drop) + L - 1) / L;
+        sd.dense_plen = dense_plen_class(need);
+        if (!sd.dense_plen) return "rows-too-long-for-dense";
     }
 
     Ctx c;

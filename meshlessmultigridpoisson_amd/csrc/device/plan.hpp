@@ -29,15 +29,16 @@
 // SIMD issues one instruction every 4 cycles, and on levels too small to fill the device that -- the
 // instruction COUNT of a tile's dependency chain -- is what a sweep costs, not bytes.  Dense plans trade
 // bytes for instructions and let Plan::waves wavefronts (one workgroup) share a tile:
-//   * every group has the same shape: 64/L row slots, exactly `plen` (Plan::dense_plen: 4 or 8) entries
-//     per lane, lane stride 64 -- every address inside a group is a compile-time offset from the group
-//     base, group g of a tile starts at g * dense_group_bytes();
+//   * every group has the same shape: 64/L row slots, exactly `plen` (Plan::dense_plen: 3, 4, 5, 7 or 8)
+//     entries per lane, lane stride 64 -- every address inside a group is a compile-time offset from the
+//     group base, group g of a tile starts at g * dense_group_bytes();
 //   * a ROUND is `waves` consecutive groups, one per wavefront, of mutually uncoupled rows; the rows of a
 //     tile are list-scheduled into rounds (a row goes into the first round after all coupled earlier
 //     rows that still has room), the wavefronts synchronise with one barrier per round;
 //   * layout of a group: RowInfo info[64/L] (16 B: RowMeta + 1/diag) | double diag[64/L] |
-//     double2 val[plen/2][64] (entries 2k, 2k+1 of a lane adjacent: one 16-byte load) |
-//     uint16 slot[plen][64] stored as plen/4 words of 8 B per lane.
+//     double2 val[plen/2][64] (entries 2k, 2k+1 of a lane adjacent: one 16-byte load), for odd plen
+//     followed by double val_last[64] | uint16 slot[64][plen], padded to dense_slot_bytes(plen) per lane
+//     (8, 12 or 16 B: one load).  dense_val_off() / dense_slot_off() below are THE definition.
 //     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
 #pragma once
 #include <cstdint>
@@ -101,18 +102,36 @@ inline size_t group_bytes(int L, int g, int plen, int bits = 16)
     return (size_t)16 * g + align16((size_t)plen * W * 8) + align16(slot_words(bits, plen) * W * 8);
 }
 
-// byte size of one group of a dense plan (16-bit slots): info + diag + values + slots
-inline size_t dense_group_bytes(int L, int plen)
+// ---- dense plans: shape of one group (16-bit slots) ----------------------------------------
+constexpr int kDensePlens[] = {3, 4, 5, 7, 8};  // entries per lane the dense kernels are instantiated for
+inline int dense_plen_class(int need)            // smallest instantiated shape holding `need` entries per lane, 0: none
 {
-    const size_t G = (size_t)(64 / L);
-    return 16 * G + 8 * G + (size_t)plen * 64 * 8 + (size_t)plen * 64 * 2;
+    for (int p : kDensePlens)
+        if (need <= p) return p;
+    return 0;
+}
+inline size_t dense_slot_bytes(int plen) { return plen <= 4 ? 8 : (plen <= 6 ? 12 : 16); }  // per lane: one load
+inline size_t dense_off_diag(int L) { return (size_t)16 * (64 / L); }
+inline size_t dense_off_val(int L) { return (size_t)24 * (64 / L); }
+inline size_t dense_off_slot(int L, int plen) { return dense_off_val(L) + (size_t)plen * 512; }
+inline size_t dense_group_bytes(int L, int plen) { return dense_off_slot(L, plen) + dense_slot_bytes(plen) * 64; }
+// byte offset (from the group base) of value / slot q of a lane
+inline size_t dense_val_off(int L, int plen, int q, int lane)
+{
+    const int pairs = plen / 2;
+    if (q < 2 * pairs) return dense_off_val(L) + (size_t)(q / 2) * 1024 + (size_t)lane * 16 + (size_t)(q % 2) * 8;
+    return dense_off_val(L) + (size_t)pairs * 1024 + (size_t)lane * 8;
+}
+inline size_t dense_slot_off(int L, int plen, int q, int lane)
+{
+    return dense_off_slot(L, plen) + (size_t)lane * dense_slot_bytes(plen) + (size_t)q * 2;
 }
 
 struct Plan {
     int L = 4;                         // lanes per row
     bool dense = false;                // dense multi-wavefront layout (see the header comment)
     int waves = 1;                     // wavefronts per tile (dense plans: groups per round)
-    int dense_plen = 0;                // entries per lane of every group (dense plans: 4 or 8)
+    int dense_plen = 0;                // entries per lane of every group (dense plans: one of kDensePlens)
     int slot_bits = 16;                // 16, or 12 when every tile has <= 4096 LDS slots (level plans, L = 2/4)
     int n_tiles = 0;
     std::vector<TileDesc> tiles;

@@ -39,7 +39,7 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
 {
     const int L = P.L, G = 64 / L, NW = P.waves, PL = P.dense_plen;
     const size_t GB = dense_group_bytes(L, PL);
-    const size_t off_diag = (size_t)16 * G, off_val = off_diag + (size_t)8 * G, off_slot = off_val + (size_t)PL * 512;
+    const size_t off_diag = dense_off_diag(L);
     const uint8_t *base = P.stream.data() + td.stream_off;
     struct Upd { RowMeta m; double acc, d, invd; };
     for (uint32_t r0 = 0; r0 < td.n_groups; r0 += (uint32_t)NW) {
@@ -62,8 +62,8 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
                     for (int q = 0; q < PL; ++q) {
                         double v;
                         uint16_t sl;
-                        std::memcpy(&v, gp + off_val + (size_t)(q / 2) * 1024 + lane * 16 + (size_t)(q % 2) * 8, 8);
-                        std::memcpy(&sl, gp + off_slot + (lane * PL + q) * 2, 2);
+                        std::memcpy(&v, gp + dense_val_off(L, PL, q, (int)lane), 8);
+                        std::memcpy(&sl, gp + dense_slot_off(L, PL, q, (int)lane), 2);
                         if (q & 1) a1 = std::fma(v, xs[sl], a1);
                         else a0 = std::fma(v, xs[sl], a0);
                     }

@@ -70,7 +70,7 @@ int main()
         }
     int fails = 0;
     struct Cfg { int tile, lanes, waves, bits; } cfgs[] = {{64, 2, 1, 12}, {100, 4, 1, 16}, {37, 8, 1, 12}, {64, 8, 3, 16},
-                                                            {128, 16, 4, 16}, {50, 4, 2, 16}, {529, 1, 1, 16}};
+                                                            {128, 16, 4, 16}, {50, 8, 2, 16}, {529, 1, 1, 16}};
     for (const Cfg &c : cfgs) {
         mmg_level_desc d{};
         d.n = n;

@@ -72,7 +72,8 @@ def test_auto_tile_points_is_device_free_arithmetic():
     assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 512
     assert _capi.auto_tile_points(54 ** 3, 3, 50, 0, 256, 163840) == 256
     assert _capi.auto_tile_points(250000, 2, 25, 0, 256, 163840) == 256
-    assert _capi.auto_tile_points(1000000, 2, 37, 0, 256, 163840) == 256  # packed stream, one residency round per phase
+    assert _capi.auto_tile_points(1000000, 2, 37, 0, 256, 163840) == 512
+    assert _capi.auto_tile_points(4000000, 2, 37, 4, 256, 163840) >= 256     # packed stream beyond the dense regime
     # mid-size levels are bound by 8 phases x one tile's duration: small tiles (measured 171^3, 190^3)
     assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 384
     assert _capi.auto_tile_points(190 ** 3, 3, 50, 0, 256, 163840) == 384

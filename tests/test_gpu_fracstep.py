@@ -69,6 +69,7 @@ def test_fracstep_3d_grid_ops_match_oracle(host):
     oc.push_inhomog(n, (rp, col, val), diag, flags, want)
     assert np.abs(want - before).max() > 0            # the coupling is not empty on this cloud
     assert np.abs(lv.get_rhs() - want).max() <= 1e-12 * np.abs(want).max()
+    g.set_source(lv.get_rhs())     # (the direct C-ABI call went past the host mirror of source_)
     # corrector with a smoothed pressure
     lvl = H.oracle_level(g.level_arrays())
     for _ in range(2):

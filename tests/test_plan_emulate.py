@@ -30,7 +30,7 @@ def test_sweeps_match_oracle(name, tile, L):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 8), (48, 16, 2)])
+@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 6), (48, 16, 3)])
 def test_dense_multiwave_layout_matches_oracle(name, tile, L, waves):
     """Dense plans (plan.hpp): fixed-shape groups, rows list-scheduled into rounds of `waves` groups.  The
     interpreter lets ALL rows of a round read before any of them writes (the wavefronts of a workgroup run a
@@ -57,18 +57,34 @@ def test_dense_multiwave_layout_matches_oracle(name, tile, L, waves):
 
 
 def test_dense_layout_falls_back_for_long_rows():
-    """Rows of more than 8 entries per lane do not fit the dense group shape: the level keeps the packed stream."""
-    import ctypes
-    case = H.load_case("dirichlet_3level")
-    la = H.level_arrays(case, 2)      # polyDeg 4: K = 37 -> 36 off-diagonal entries, 9 per lane at L = 4
-    e = H.EmuLevel(la, tile_size=64, lanes_per_row=4, waves_per_tile=4)
+    """Rows of more than 8 entries per lane (here 150 entries: 10 per lane at 16 lanes) do not fit any dense group
+    shape: the level keeps the packed stream, results unchanged.  A request for 4 lanes per row is served with the
+    dense layout's own choice (8 or 16 lanes)."""
+    rng = np.random.default_rng(2)
+    n, k = 220, 150
+    rowptr, col, val = [0], [], []
+    for i in range(n):
+        c = np.sort(rng.choice(np.delete(np.arange(n), i), size=k - 1, replace=False))
+        c = np.sort(np.append(c, i))
+        v = -rng.random(k)
+        v[c == i] = k + 1.0
+        col += c.tolist()
+        val += v.tolist()
+        rowptr.append(len(col))
+    la = dict(n=n, a_size=n, rowptr=np.array(rowptr, dtype=np.int32), col=np.array(col, dtype=np.int32), val=np.array(val),
+              bcflags=np.zeros(n, dtype=np.int32), neumann=0, omega=1.2, iters=2, btype=np.zeros(0, dtype=np.int32),
+              bptr=np.zeros(1, dtype=np.int32), bpts=np.zeros(0, dtype=np.int32), bvals=np.zeros(0),
+              x0=np.zeros(n), b0=rng.standard_normal(n))
+    e = H.EmuLevel(la, tile_size=64, lanes_per_row=16, waves_per_tile=4)
     lib = H.emu_lib()
-    lib.emu_level_waves.argtypes = [ctypes.c_void_p]
     assert lib.emu_level_waves(e.h) == 0
     o = H.oracle_level(la)
     o.sor_sweeps(2)
     e.sweeps(2)
     assert H.rel_err(e.x, o.x) < 1e-12
+    case = H.load_case("dirichlet_3level")
+    e4 = H.EmuLevel(H.level_arrays(case, 2), tile_size=64, lanes_per_row=4, waves_per_tile=4)   # K = 37
+    assert lib.emu_level_waves(e4.h) == 4
 
 
 @pytest.mark.parametrize("name", ["neumann_2level", "neumann_3level"])
