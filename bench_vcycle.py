@@ -26,10 +26,14 @@ def main():
     ap.add_argument("--omega", type=float, default=1.4, help="SOR factor (reference default 1.4, testing_functions.cpp)")
     ap.add_argument("--iters", type=int, default=5, help="sweeps per smoothing call (reference default 5)")
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
+    ap.add_argument("--graph", type=int, default=1, help="0: issue every launch of the cycle body directly (A/B of the HIP graph)")
+    ap.add_argument("--waves", type=int, default=0, help="waves_per_tile option: 0 automatic, 1 packed stream everywhere (A/B)")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
     _capi.set_option("persistent_sweep", a.persistent)
     _capi.set_option("lds_resident", a.lds_resident)
+    _capi.set_option("vcycle_graph", a.graph)
+    _capi.set_option("waves_per_tile", a.waves)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
     if a.dim == 3:

@@ -119,7 +119,13 @@ int mmg_get_counter(const char *name, long long *value);
  * separately rounded multiply/add and the norms/multiplier row are summed sequentially:
  * iterates and residual histories are then bitwise those of the sequential CPU loops
  * (grid.cpp:104-151, multigrid.cpp:62-115).  Slow; proves the schedule is the
- * reference's Gauss-Seidel order. */
+ * reference's Gauss-Seidel order.
+ * "waves_per_tile": layout of levels created afterwards whose descriptor leaves it 0 -- 0 automatic (by
+ * level size and stencil width), 1 packed stream, 2 / 3 / 4 / 6 dense multi-wavefront layout.
+ * "vcycle_graph" (default 0): 1: after one plain run the body of mmg_vcycle (everything after the residual
+ * ratio: ~60 short launches) is captured into a HIP graph and replayed; re-captured when an option, omega /
+ * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on MI355X (the
+ * asynchronous launches never starve the stream), hence off by default. */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);

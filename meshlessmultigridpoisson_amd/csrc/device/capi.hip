@@ -42,6 +42,12 @@ thread_local bool g_own_stream = false;
 // level or a hierarchy (settle / settle_hierarchy below).
 unsigned *g_err_host = nullptr, *g_err_dev = nullptr;
 int g_waves = 0;  // mmg_set_option("waves_per_tile", n): layout of levels created afterwards whose descriptor says 0 -- 0 automatic, 1 packed stream, 2 / 4 / 8 dense
+// mmg_set_option("vcycle_graph", 0 | 1): replay the V-cycle body as a HIP graph (single-GPU hierarchies).  Off by
+// default: same-box A/B on BASELINE configs[1] (2-D 1e6 points, 5 levels, ~60 launches per cycle): 2.97 ms with the
+// graph, 2.93 ms without -- the launches are asynchronous, the host runs ahead and the stream is never starved.
+int g_graph = 0;
+thread_local bool g_capturing = false;  // inside hipStreamBeginCapture ... EndCapture of a cycle body
+unsigned long long g_state_gen = 1;     // bumped by everything a captured cycle body depends on besides its data
 int g_spin_bound = 1 << 22;        // mmg_set_option("debug_spin_bound", n): test hook, 0 makes every wait fail
 long long g_sweep_fallbacks = 0;   // mmg_get_counter("sweep_fallbacks")
 
@@ -306,6 +312,15 @@ struct mmg_hierarchy {
     int frac_step = 0;
     DevBuf<double> x_backup;  // fine-level x at the start of the unchecked cycle body
     bool unsettled = false;   // the last cycle body used dependency-driven launches and has not been checked yet
+    // the cycle body as a HIP graph (run_cycle_body): ~60 launches of a few microseconds each on the small levels
+    hipGraphExec_t gexec = nullptr;
+    unsigned long long ggen = 0;  // g_state_gen at capture
+    int plain_runs = 0;           // the first body runs un-captured: lazy allocations happen there
+    bool graph_failed = false;
+    ~mmg_hierarchy()
+    {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+    }
 };
 
 struct mmg_fracstep {
@@ -414,6 +429,23 @@ int mark_event()
     return MMG_OK;
 }
 
+// Epoch of the flags of a dependency-driven launch.  Normally the flags only grow (epoch = sweeps launched so
+// far on the level).  Inside a graph capture the arguments are frozen, so the flags are zeroed by a memset node
+// in front of the launch and the epoch restarts at 1 every time.
+int sweep_epoch(mmg_level *lv, int ns, TileArgs *a)
+{
+    a->n_sweeps = ns;
+    if (g_capturing) {
+        HIPC(hipMemsetAsync(lv->sync_words.p + 2, 0, sizeof(unsigned) * (size_t)lv->A.n_tiles, g_stream));
+        a->epoch = 1u;
+        lv->epoch = 0x40000000u;  // whatever runs un-captured afterwards starts far above the replayed values
+    } else {
+        a->epoch = lv->epoch + 1;
+        lv->epoch += (unsigned)ns;
+    }
+    return MMG_OK;
+}
+
 int sweep_some(mmg_level *lv, int k, int *done)
 {
     int erc;
@@ -435,9 +467,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         a.done = lv->sync_words.p + 2;
         const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
         const int ns = fusable ? std::min(k, 16) : 1;
-        a.epoch = lv->epoch + 1;
-        a.n_sweeps = ns;
-        lv->epoch += (unsigned)ns;
+        if ((erc = sweep_epoch(lv, ns, &a))) return erc;
         if ((erc = mark_event())) return erc;
         if (lv->A.dev.dense) HIPC(launch_sweep_resident_mw(a, g_stream));
         else
@@ -456,9 +486,7 @@ int sweep_some(mmg_level *lv, int k, int *done)
         // boundary solve, no ghost exchange): the queue simply runs over sweeps x tiles
         const bool fusable = !lv->neumann && lv->B.empty() && !lv->distributed;
         const int ns = fusable ? std::min(k, 16) : 1;
-        a.epoch = lv->epoch + 1;
-        a.n_sweeps = ns;
-        lv->epoch += (unsigned)ns;
+        if ((erc = sweep_epoch(lv, ns, &a))) return erc;
         a.fence = g_persistent_sweep == 2;
         HIPC(hipMemsetAsync(lv->sync_words.p, 0, sizeof(unsigned), g_stream));
         if ((erc = mark_event())) return erc;
@@ -543,6 +571,7 @@ int settle(mmg_level *lv)
     int rc = read_error_word(lv->distributed, &failed);
     if (rc || !failed) return rc;
     ++g_sweep_fallbacks;
+    ++g_state_gen;
     lv->safe_mode = true;
     HIPC(hipMemcpyAsync(lv->x.p, lv->x_backup.p, sizeof(double) * (size_t)lv->a_size, hipMemcpyDeviceToDevice, g_stream));
     return sweeps(lv, k);  // one launch per phase now: nothing left to check
@@ -799,12 +828,52 @@ int cycle_body(mmg_hierarchy *h)
     return MMG_OK;
 }
 
-int run_cycle_body(mmg_hierarchy *h)
+int run_cycle_body_plain(mmg_hierarchy *h)
 {
     for (mmg_level *l : h->lv) l->in_cycle = true;  // the hierarchy checks, not the levels
     const int rc = cycle_body(h);
     for (mmg_level *l : h->lv) l->in_cycle = false;
     return rc;
+}
+
+// The body of a V-cycle is the same sequence of ~60 launches every time (the host decides nothing inside
+// it); on the small levels a launch is shorter than the host needs to issue it.  After one plain run it is
+// captured once into a HIP graph and replayed when mmg_set_option("vcycle_graph", 1) asks for it.  The
+// capture is redone whenever something it froze changes (options, omega / iters, boundary data buffers,
+// a level dropping to per-phase launches): g_state_gen.  Distributed hierarchies are not captured (RCCL
+// calls inside the body).
+int run_cycle_body(mmg_hierarchy *h)
+{
+    bool eligible = g_graph != 0 && !h->graph_failed && g_sweep_events == nullptr;
+    for (mmg_level *l : h->lv) eligible = eligible && !l->distributed;
+    if (!eligible || h->plain_runs < 1) {
+        ++h->plain_runs;
+        return run_cycle_body_plain(h);
+    }
+    if (!h->gexec || h->ggen != g_state_gen) {
+        if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            h->graph_failed = true;
+            return run_cycle_body_plain(h);
+        }
+        g_capturing = true;
+        const int rc = run_cycle_body_plain(h);
+        g_capturing = false;
+        const hipError_t e = hipStreamEndCapture(g_stream, &graph);
+        if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            h->gexec = nullptr;
+            h->graph_failed = true;   // nothing ran: the body is issued directly from now on
+            (void)hipGetLastError();
+            return rc ? rc : run_cycle_body_plain(h);
+        }
+        (void)hipGraphDestroy(graph);
+        h->ggen = g_state_gen;
+    }
+    HIPC(hipGraphLaunch(h->gexec, g_stream));
+    return MMG_OK;
 }
 
 // A cycle body whose dependency-driven launches failed is repeated from the fine-level x it started
@@ -814,6 +883,7 @@ int repair_cycle(mmg_hierarchy *h)
 {
     mmg_level *fine = h->lv.back();
     ++g_sweep_fallbacks;
+    ++g_state_gen;
     for (mmg_level *l : h->lv) l->safe_mode = true;
     HIPC(hipMemcpyAsync(fine->x.p, h->x_backup.p, sizeof(double) * (size_t)fine->a_size, hipMemcpyDeviceToDevice, g_stream));
     return run_cycle_body(h);
@@ -896,6 +966,8 @@ int mmg_set_stream(void *hip_stream)
 int mmg_set_option(const char *name, int value)
 {
     if (!name) return fail(MMG_ERR_INVALID, "null option");
+    ++g_state_gen;
+    if (std::strcmp(name, "vcycle_graph") == 0) { g_graph = value; return MMG_OK; }
     if (std::strcmp(name, "persistent_sweep") == 0) { g_persistent_sweep = value; return MMG_OK; }
     if (std::strcmp(name, "exact_arithmetic") == 0) { g_exact = value != 0; return MMG_OK; }
     if (std::strcmp(name, "slot_bits") == 0) { g_slot_bits = value == 12 ? 12 : 16; return MMG_OK; }
@@ -959,7 +1031,8 @@ namespace {
 // least phases x (one tile's dependency chain) ~ phases x 40 us however small the level; the dense layout
 // runs the chain ~5x faster but moves 1.5-2x the bytes (row slots and entry slots that stay empty).
 // Measured crossovers (MI355X, us per sweep, dense vs packed): 3-D K = 50: 27^3 69 / 250, 54^3 86 / 290,
-// 108^3 217 / 382, 128^3 357 / 473, 150^3 510 / 553; 2-D K = 25: 500^2 39 / 57; 2-D K = 37: 1000^2 161 / 147.
+// 108^3 217 / 382, 128^3 357 / 473, 150^3 510 / 553; 2-D K = 25: 500^2 39 / 57; 2-D K = 37: 1000^2 118 / 147
+// (8 lanes x 5 entries, 512-point tiles, 2 wavefronts; 161 with 8 entries per lane).
 struct LevelLayout {
     bool dense;
     int tile_points, lanes, waves;
@@ -968,7 +1041,7 @@ LevelLayout level_layout(long long n_points, double avg_row_len)
 {
     if (avg_row_len >= 44.0) {  // 3-D stencils (K = 50): 8 tile colours, ~23 dependency levels per tile
         if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows, 4 entries per lane
-        if (n_points <= 3000000) return {true, 512, 8, 3};    // bandwidth starts to matter: 7 of 7 entry slots used, rounds of 3 x 8 rows
+        if (n_points <= 3000000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217-224 us; 8 lanes x 7 entries: 293)
         return {false, 0, 0, 1};
     }
     if (avg_row_len <= 30.0) {  // 2-D K = 25 (the coarse levels of the reference's hierarchies)
@@ -976,7 +1049,7 @@ LevelLayout level_layout(long long n_points, double avg_row_len)
         return {false, 0, 0, 1};
     }
     if (n_points <= 300000) return {true, 256, 8, 2};          // 2-D K = 37 ... 70, small: short chains
-    if (n_points <= 1500000) return {true, 512, 8, 3};         // 2-D K = 37: 5 entries per lane (36 of 40 slots), full rounds
+    if (n_points <= 1500000) return {true, 512, 8, 2};         // 2-D K = 37: 5 entries per lane (36 of 40 slots): 1000^2 118 us (packed 147)
     return {false, 0, 0, 1};
 }
 }  // namespace
@@ -1211,6 +1284,7 @@ LEVEL_VEC_IO(mmg_level_get_rhs, b, )
 int mmg_level_set_bvals(mmg_level *lv, const double *bvals, int count)
 {
     if (!lv || !bvals || count != (int)lv->bpts.size()) return fail(MMG_ERR_INVALID, "set_bvals: bad size");
+    ++g_state_gen;
     HIPC(hipStreamSynchronize(g_stream));
     return upload_bvals(lv, bvals);
 }
@@ -1219,6 +1293,7 @@ int mmg_level_set_omega_iters(mmg_level *lv, double omega, int iters)
 {
     if (!lv) return fail(MMG_ERR_INVALID, "null level");
     if (int src_ = settle(lv)) return src_;
+    if (lv->omega != omega || lv->iters != iters) ++g_state_gen;
     lv->omega = omega;
     lv->iters = iters;
     return MMG_OK;

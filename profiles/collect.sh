@@ -11,6 +11,8 @@ tag=${1:?tag}
 root=$(pwd)
 out=$root/gpurun_out
 export TMPDIR=/tmp
+# (the run includes the two whole-V-cycle legs: the kernel statistics then also show the dense multi-wavefront
+#  kernels of the small levels, the residual and the transfer kernels)
 cmd="$root/bench.py --steps 16 --warmup 16 --no-cpu"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $cmd > $out/${tag}_profiled_run_bench.json 2> $out/${tag}_stats.log

@@ -37,7 +37,7 @@ def main():
     write = agg_counter(write_dir, "WRITE_SIZE")
     lines = [f"# {tag}: rocprofv3 summary", "",
              "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
-    for r in rows[:8]:
+    for r in rows[:16]:
         lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | "
                      f"{float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |")
     lines += ["", "| kernel | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | HBM MB/launch (2*F+W) |", "|---|---|---|---|"]
@@ -48,7 +48,7 @@ def main():
         fm = sum(fetch[k]) / len(fetch[k])
         wm = sum(write[k]) / len(write[k])
         mb = (2 * fm + wm) * 1024 / 1e6
-        if ("tile_kernel" in k or "sweep_persistent" in k) and (traffic is None or mb > traffic):
+        if ("tile_kernel" in k or "sweep_persistent_kernel" in k) and (traffic is None or mb > traffic):
             traffic = mb
         lines.append(f"| `{k[:70]}` | {fm:.0f} | {wm:.0f} | {mb:.1f} |")
     if bench:

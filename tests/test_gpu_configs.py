@@ -205,3 +205,32 @@ def test_failed_dependency_wait_falls_back_to_phase_launches(name):
     finally:
         _capi.set_option("debug_spin_bound", -1)
         _capi.set_option("persistent_sweep", 1)
+
+
+def test_vcycle_body_as_hip_graph_changes_no_bit():
+    """mmg_set_option("vcycle_graph", 1): the cycle body is captured into a HIP graph after one plain run and
+    replayed -- the same launches with the same arguments, so the same bits as issuing them directly, also after a
+    re-capture (omega changed) and next to un-captured sweeps on the same levels."""
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case("dirichlet_3level")
+    om = H.oracle_multigrid(case)
+    def run():
+        h = H.device_hierarchy(case)
+        r = [h.vcycle() for _ in range(3)]     # (graph: plain run, capture + replay, replay)
+        h.levels[0].sweeps(1)                  # an un-captured launch on a level of the graph in between
+        res, _ = h.vcycles(3)                  # batched entry: replays again
+        return h, r + list(res)
+
+    _capi.set_option("vcycle_graph", 0)
+    plain, rp = run()
+    _capi.set_option("vcycle_graph", 1)
+    try:
+        dh, rg = run()
+        assert rg == rp
+        for k in range(3):
+            ro = om.vcycle()
+            assert abs(rg[k] - ro) <= 1e-10 * ro + FLOOR
+        assert np.array_equal(dh.levels[-1].get_x(), plain.levels[-1].get_x())
+    finally:
+        _capi.set_option("vcycle_graph", 0)
+
