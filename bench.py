@@ -208,8 +208,8 @@ def spawn_ranks(a):
 
 def main():
     a = parse()
-    if a.gpus > 1 and "RANK" not in os.environ:
-        spawn_ranks(a)   # does not return
+    if (a.gpus > 1 or a.force_dd) and "RANK" not in os.environ:
+        spawn_ranks(a)   # does not return (--force-dd: the same path with one rank, rehearsal on a 1-GPU box)
     # stdout carries exactly ONE JSON line.  RCCL prints a version banner on stdout when a communicator is
     # created (torch's and the library's own): everything but the final line goes to stderr.
     sys.stdout.flush()

@@ -1176,8 +1176,8 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
             waves = ll.dense ? ll.waves : 1;
             if (ll.dense && d->lanes_per_row <= 0) dd.lanes_per_row = ll.lanes;
         }
-        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6))
-            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4 or 6");
+        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8 || waves == 12))
+            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4, 6, 8 or 12");
         const std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;

@@ -417,6 +417,12 @@ hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t 
     case 3: return launch_mw_LPN<L, P, 3>(k, a, workers, s, occ);
     case 4: return launch_mw_LPN<L, P, 4>(k, a, workers, s, occ);
     case 6: return launch_mw_LPN<L, P, 6>(k, a, workers, s, occ);
+    case 8:   // wide workgroups: the 3-D shape only (16 lanes x 4 entries), for large tiles on bandwidth-limited levels
+        if constexpr (L == 16 && P == 4) return launch_mw_LPN<L, P, 8>(k, a, workers, s, occ);
+        break;
+    case 12:
+        if constexpr (L == 16 && P == 4) return launch_mw_LPN<L, P, 12>(k, a, workers, s, occ);
+        break;
     }
     return hipErrorInvalidValue;
 }
