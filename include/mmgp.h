@@ -72,7 +72,7 @@ typedef struct {
                               sub-domains pass the GLOBAL tile colours so that every rank numbers its
                               phases alike (mmg_level_set_exchange_mode)        */
     int waves_per_tile;    /* 0: automatic; 1: one wavefront per tile, packed stream (the streaming layout of
-                              levels far larger than the device); 2, 3, 4, 6: dense layout, that many wavefronts
+                              levels far larger than the device); 2, 3, 4, 6 (8, 12 for 16 lanes x 4 entries): dense layout, that many wavefronts
                               share a tile and synchronise once per round of mutually uncoupled rows -- for
                               levels whose sweep is bound by the dependency chain of a tile, not by bytes   */
 } mmg_level_desc;

@@ -1041,7 +1041,9 @@ LevelLayout level_layout(long long n_points, double avg_row_len)
 {
     if (avg_row_len >= 44.0) {  // 3-D stencils (K = 50): 8 tile colours, ~23 dependency levels per tile
         if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows, 4 entries per lane
-        if (n_points <= 3000000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217-224 us; 8 lanes x 7 entries: 293)
+        if (n_points <= 1500000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217-224 us; 8 lanes x 7 entries: 293)
+        if (n_points <= 2600000) return {true, 1024, 16, 12}; // 128^3: 312 us (T 384 / 4 wavefronts: 357; packed 473)
+        if (n_points <= 4000000) return {true, 1024, 16, 6};  // 150^3: 451 us = 56 % (T 512: 502; packed 553)
         return {false, 0, 0, 1};
     }
     if (avg_row_len <= 30.0) {  // 2-D K = 25 (the coarse levels of the reference's hierarchies)

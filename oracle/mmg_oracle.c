@@ -95,6 +95,79 @@ void orc_sor_sweeps(orc_level *g, int nsweeps)
 /* grid.cpp:104-146  Grid::sor */
 void orc_sor(orc_level *g) { orc_sor_sweeps(g, g->iters); }
 
+/* ---- colour-parallel CPU sweep: "baseline only"  -------------------------
+ * The reference is strictly sequential.  With the multicolour tile ordering of the port
+ * (Grid::mc_order_points) tiles of one colour are mutually uncoupled, so a sweep in storage order equals:
+ * for each colour, relax its tiles -- rows inside a tile in storage order -- in any order or concurrently.
+ * This runs the tiles of a colour on `nthreads` POSIX threads; bitwise the sequential sweep (Dirichlet levels:
+ * no multiplier row, no Neumann boundary solve).  tile_ptr[n_tiles + 1] point ranges, tile_phase[n_tiles]. */
+#include <pthread.h>
+typedef struct {
+    orc_level *g;
+    const int *tile_ptr, *tile_phase, *order;  /* order: tiles sorted by phase; phase_ptr into it */
+    const int *phase_ptr;
+    int n_phases, nthreads, nsweeps;
+    volatile int next;
+    pthread_barrier_t bar;
+} orc_par;
+
+static void relax_range(orc_level *g, int i0, int i1)
+{
+    for (int i = i0; i < i1; ++i) {
+        if (g->bcflags[i] != 0) continue;
+        double xi = 0.0, diag = 0.0;
+        for (int p = g->rowptr[i]; p < g->rowptr[i + 1]; ++p) {
+            const int j = g->col[p];
+            if (j == i) { diag = g->val[p]; continue; }
+            xi -= g->val[p] * g->x[j];
+        }
+        xi += g->b[i];
+        xi *= g->omega / diag;
+        xi += (1 - g->omega) * g->x[i];
+        g->x[i] = xi;
+    }
+}
+
+static void *par_worker(void *arg)
+{
+    orc_par *P = (orc_par *)arg;
+    for (int it = 0; it < P->nsweeps; ++it)
+        for (int ph = 0; ph < P->n_phases; ++ph) {
+            for (;;) {
+                const int k = __sync_fetch_and_add(&P->next, 1);
+                if (k >= P->phase_ptr[ph + 1]) break;
+                const int t = P->order[k];
+                relax_range(P->g, P->tile_ptr[t], P->tile_ptr[t + 1]);
+            }
+            const int r = pthread_barrier_wait(&P->bar);
+            if (r == PTHREAD_BARRIER_SERIAL_THREAD) P->next = P->phase_ptr[ph + 1 < P->n_phases ? ph + 1 : 0];
+            pthread_barrier_wait(&P->bar);
+        }
+    return 0;
+}
+
+int orc_sor_sweeps_tiled(orc_level *g, int nsweeps, const int *tile_ptr, int n_tiles, const int *tile_phase,
+                         int n_phases, int nthreads)
+{
+    if (g->neumann_flag || n_tiles < 1 || n_phases < 1 || nthreads < 1) return 1;
+    int *order = (int *)malloc(sizeof(int) * (size_t)n_tiles), *pp = (int *)calloc((size_t)n_phases + 1, sizeof(int));
+    for (int t = 0; t < n_tiles; ++t) pp[tile_phase[t] + 1]++;
+    for (int p = 0; p < n_phases; ++p) pp[p + 1] += pp[p];
+    int *cur = (int *)malloc(sizeof(int) * (size_t)n_phases);
+    for (int p = 0; p < n_phases; ++p) cur[p] = pp[p];
+    for (int t = 0; t < n_tiles; ++t) order[cur[tile_phase[t]]++] = t;
+    orc_par P;
+    P.g = g; P.tile_ptr = tile_ptr; P.tile_phase = tile_phase; P.order = order; P.phase_ptr = pp;
+    P.n_phases = n_phases; P.nthreads = nthreads; P.nsweeps = nsweeps; P.next = 0;
+    pthread_barrier_init(&P.bar, 0, (unsigned)nthreads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for (int i = 0; i < nthreads; ++i) pthread_create(&th[i], 0, par_worker, &P);
+    for (int i = 0; i < nthreads; ++i) pthread_join(th[i], 0);
+    pthread_barrier_destroy(&P.bar);
+    free(th); free(order); free(pp); free(cur);
+    return 0;
+}
+
 /* grid.cpp:147-151  Grid::residual -- r = source_ - laplaceMat_*values_
  * (Eigen row-major product: per row, accumulate in stored (ascending column)
  * order, then subtract), then Dirichlet entries zeroed. */

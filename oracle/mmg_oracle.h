@@ -107,6 +107,10 @@ void orc_fs_set_ppe_source3(int n, const orc_csr *dx, const orc_csr *dy, const o
 void orc_fs_correct3(int n, const orc_csr *dx, const orc_csr *dy, const orc_csr *dz, const double *p,
                      const double *u_hat, const double *v_hat, const double *w_hat, double dt, double rho, double *u,
                      double *v, double *w);
+/* colour-parallel CPU sweep over the port's multicolour tiles ("baseline only": the reference is sequential);
+ * bitwise orc_sor_sweeps on Dirichlet levels; returns non-zero when the level is not eligible */
+int orc_sor_sweeps_tiled(orc_level *g, int nsweeps, const int *tile_ptr, int n_tiles, const int *tile_phase,
+                         int n_phases, int nthreads);
 void orc_push_inhomog(int n, const orc_csr *bc, const double *diags, const int *bcflags, double *source);
 #ifdef __cplusplus
 }

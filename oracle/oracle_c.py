@@ -85,6 +85,7 @@ def lib(fast=False):
                                              _ip, C.c_int, _dp, _dp, _dp, _dp]
         L.orc_fs_correct3.argtypes = [C.c_int, pc, pc, pc, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp]
         L.orc_push_inhomog.argtypes = [C.c_int, pc, _dp, _ip, _dp]
+        L.orc_sor_sweeps_tiled.argtypes = [C.POINTER(_Level), C.c_int, _ip, C.c_int, _ip, C.c_int, C.c_int]
         _libs[name] = L
     return _libs[name]
 
@@ -148,6 +149,14 @@ class Level:
     def sor_sweeps(self, k):
         s = self.struct()
         lib(self.fast).orc_sor_sweeps(C.byref(s), int(k))
+
+    def sor_sweeps_tiled(self, k, tile_ptr, tile_phase, nthreads):
+        """colour-parallel sweeps over multicolour tiles (baseline only); bitwise sor_sweeps on Dirichlet levels"""
+        s = self.struct()
+        tp, ph = _i(tile_ptr), _i(tile_phase)
+        rc = lib(self.fast).orc_sor_sweeps_tiled(C.byref(s), int(k), _pi(tp), len(tp) - 1, _pi(ph), int(ph.max()) + 1, int(nthreads))
+        if rc:
+            raise ValueError("level not eligible for the colour-parallel sweep")
 
     def sor_hybrid(self, part, nparts, k):
         s = self.struct()

@@ -69,7 +69,8 @@ def test_auto_tile_points_is_device_free_arithmetic():
     assert _capi.auto_tile_points(10077696, 3, 50, 2, 256, 163840) == 1280
     assert _capi.auto_tile_points(10077696, 3, 50, 0, 256, 163840) == 1280  # lanes 0: as mmg_level_create picks L
     # latency-bound levels take the dense multi-wavefront layout (capi.hip: level_layout): its tile sizes
-    assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 512
+    assert _capi.auto_tile_points(2000000, 3, 50, 2, 256, 163840) == 1024
+    assert _capi.auto_tile_points(108 ** 3, 3, 50, 0, 256, 163840) == 512
     assert _capi.auto_tile_points(54 ** 3, 3, 50, 0, 256, 163840) == 256
     assert _capi.auto_tile_points(250000, 2, 25, 0, 256, 163840) == 256
     assert _capi.auto_tile_points(1000000, 2, 37, 0, 256, 163840) == 512

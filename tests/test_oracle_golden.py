@@ -131,3 +131,20 @@ def test_oracle_3d_fracstep_statements_against_numpy():
     oc.push_inhomog(n, csr[0], diag, flags, b)
     assert np.allclose(b, want, rtol=1e-14, atol=1e-15)
 
+
+def test_colour_parallel_cpu_sweep_is_bitwise_the_sequential_one():
+    """bench.py's optional all-cores CPU figure ("baseline only"): the tiles of one colour of the port's multicolour
+    ordering relaxed concurrently on POSIX threads must give exactly the reference's sequential sweep."""
+    from meshlessmultigridpoisson_amd import _host as host
+    pts = host.box_cloud(14, 3, seed=3)
+    g = host.Grid.create_square(pts, 2, dim=3, kind=host.KIND_GRAPH, ordering=host.ORDER_MC, tile_points=128)
+    la = g.level_arrays()
+    la["b0"] = np.random.default_rng(1).standard_normal(la["a_size"])
+    tp = g.tile_ptr()
+    ph, _gm = H.EmuLevel(la, tile_ptr=tp, lanes_per_row=4).point_phases()
+    tile_phase = np.array([max(0, ph[tp[t]:tp[t + 1]].max(initial=0)) for t in range(len(tp) - 1)], dtype=np.int32)
+    seq, par = H.oracle_level(la), H.oracle_level(la)
+    seq.sor_sweeps(3)
+    par.sor_sweeps_tiled(3, tp, tile_phase, 4)
+    assert np.array_equal(seq.x, par.x)
+
