@@ -233,6 +233,15 @@ int mmg_prolong_add(mmg_level *coarse, mmg_level *fine, mmg_transfer *P);
 int mmg_hierarchy_create(mmg_hierarchy **out, mmg_level **levels, int nlevels,
                          mmg_transfer **R, mmg_transfer **P, int frac_step);
 void mmg_hierarchy_destroy(mmg_hierarchy *h);
+/* Multi-GPU, replicated coarse levels ("agglomeration"): levels 0 .. level-1 of the hierarchy are
+ * complete copies on every rank (NOT registered with mmg_level_set_exchange: they are relaxed without any
+ * communication, identically everywhere), levels >= level are decomposed.  The restriction R[level] into the
+ * finest replicated level then has one column per GLOBAL point of level `level`; before it is applied the ranks
+ * all-gather their owned residual entries: gid_all[q * max_count + k] = global index of the k-th owned point of
+ * rank q (-1 padding up to max_count = the largest owned count), n_global = points of the decomposed level in
+ * total.  The prolongation out of the replicated level needs no exchange (its input is complete everywhere).
+ * Collective in effect (every rank registers the same lists). */
+int mmg_hierarchy_set_gather(mmg_hierarchy *h, int level, int nranks, int max_count, const int *gid_all, int n_global);
 /* Multigrid::vCycle  multigrid.cpp:62-110 ; *resid_before = residuals_.back()
  * (-1 for the frac-step single-grid early-out, which pushes nothing) */
 int mmg_vcycle(mmg_hierarchy *h, double *resid_before);

@@ -52,6 +52,7 @@ SYMBOLS = [
     "mmg_fracstep_set", "mmg_fracstep_get", "mmg_fracstep_calc_hat", "mmg_fracstep_set_ppe_source",
     "mmg_fracstep_correct", "mmg_fracstep_residual", "mmg_fracstep_create_3d", "mmg_fracstep_set_bound_values",
     "mmg_fracstep_apply_bound", "mmg_fracstep_step", "mmg_level_set_neumann_coupling", "mmg_level_push_inhomog_to_rhs",
+    "mmg_hierarchy_set_gather",
 ]
 
 _lib = None

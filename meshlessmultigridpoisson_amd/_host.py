@@ -83,6 +83,11 @@ def lib():
         L.mmgh_grid_knn.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_fs_create_square.restype = vp
         L.mmgh_fs_create_square.argtypes = [C.c_int, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "mmgh_mg_extract_subdomain_replicated"):
+            L.mmgh_mg_extract_subdomain_replicated.restype = vp
+            L.mmgh_mg_extract_subdomain_replicated.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+            L.mmgh_mg_gather_info.argtypes = [vp, _ip, _ip]
+            L.mmgh_grid_is_replicated.argtypes = [vp]
         if hasattr(L, "mmgh_fs_create_box"):  # (absent from older builds loaded through MMGP_LIBDIR for A/B runs)
             L.mmgh_fs_create_box.restype = vp
             L.mmgh_fs_create_box.argtypes = [C.c_int, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
@@ -215,6 +220,9 @@ class Grid:
         g = cls(h)
         g._own = True
         return g
+
+    def is_replicated(self):
+        return bool(lib().mmgh_grid_is_replicated(self.h))
 
     def local_map(self):
         """(n_owned, gid[n_local], ghost_owner[n_ghost]) of a sub-domain grid."""
@@ -464,12 +472,27 @@ class Multigrid:
         self.h, self.omega, self.iters, self.residuals, self.frac_step = h, omega, iters, [], False
         return self
 
-    def extract_subdomain(self, nparts, rank):
-        """Rank's sub-domain of every level + the local rows of the transfers (host C++)."""
-        h = lib().mmgh_mg_extract_subdomain(self.h, int(nparts), int(rank))
+    def extract_subdomain(self, nparts, rank, replicate_below=0):
+        """Rank's sub-domain of every level + the local rows of the transfers (host C++).  replicate_below > 0:
+        coarse levels of at most that many points stay complete on every rank (no exchange on them; the
+        restriction into them reads the all-gathered residual of the coarsest decomposed level)."""
+        if replicate_below > 0:
+            h = lib().mmgh_mg_extract_subdomain_replicated(self.h, int(nparts), int(rank), int(replicate_below))
+        else:
+            h = lib().mmgh_mg_extract_subdomain(self.h, int(nparts), int(rank))
         if not h:
             raise HostError(_err())
         return Multigrid._from_handle(h, self.omega, self.iters)
+
+    def gather_info(self):
+        """(level, ranks, max_count, n_global, gid[ranks, max_count]) of a hierarchy with replicated coarse levels, or None."""
+        o = np.zeros(4, dtype=np.int32)
+        lib().mmgh_mg_gather_info(self.h, o.ctypes.data_as(_ip), None)
+        if o[0] < 0:
+            return None
+        gid = np.zeros(int(o[1]) * int(o[2]), dtype=np.int32)
+        lib().mmgh_mg_gather_info(self.h, o.ctypes.data_as(_ip), gid.ctypes.data_as(_ip))
+        return int(o[0]), int(o[1]), int(o[2]), int(o[3]), gid.reshape(int(o[1]), int(o[2]))
 
     def level_part(self, l, nparts):
         part = np.zeros(self.grid(l).sizes()["n"], dtype=np.int32)
@@ -484,6 +507,8 @@ class Multigrid:
         from . import _capi
         for l in range(self.nlevels):
             g = self.grid(l)
+            if g.is_replicated():      # a complete copy on every rank: relaxed without any exchange
+                continue
             no, gid, gown = g.local_map()
             nbr, sp, si, rp = build_exchange_lists(rank, no, gid, gown, all_gather_object)
             s = g.sizes()

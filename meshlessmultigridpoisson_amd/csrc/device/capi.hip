@@ -95,6 +95,7 @@ struct Rccl {
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
@@ -121,6 +122,7 @@ int rccl_load()
     RSYM(Send, "ncclSend")
     RSYM(Recv, "ncclRecv")
     RSYM(AllReduce, "ncclAllReduce")
+    RSYM(AllGather, "ncclAllGather")
     RSYM(GetErrorString, "ncclGetErrorString")
 #undef RSYM
     return MMG_OK;
@@ -312,6 +314,12 @@ struct mmg_hierarchy {
     int frac_step = 0;
     DevBuf<double> x_backup;  // fine-level x at the start of the unchecked cycle body
     bool unsettled = false;   // the last cycle body used dependency-driven launches and has not been checked yet
+    // Replicated coarse levels (mmg_hierarchy_set_gather): levels below `gather_level` are complete copies on
+    // every rank, relaxed without any exchange; the restriction INTO them reads the all-gathered residual of
+    // level `gather_level` (the coarsest decomposed one) in global numbering
+    int gather_level = -1, gather_ranks = 0, gather_max = 0, gather_nglobal = 0;
+    DevBuf<int32_t> gather_gid;            // [gather_ranks * gather_max]: global index of rank q's k-th owned point, -1 padding
+    DevBuf<double> gsend, grecv, gvec;     // owned residuals (padded), everybody's, the global-order vector
     // the cycle body as a HIP graph (run_cycle_body): ~60 launches of a few microseconds each on the small levels
     hipGraphExec_t gexec = nullptr;
     unsigned long long ggen = 0;  // g_state_gen at capture
@@ -741,16 +749,34 @@ int upload_bvals(mmg_level *lv, const double *bvals)
     return MMG_OK;
 }
 
-int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R)
+int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R, mmg_hierarchy *h = nullptr, int level = -1)
 {
-    if (R->rows != coarse->n || R->cols != fine->n) return fail(MMG_ERR_INVALID, "restrict: shape mismatch");
+    const bool gather = h && h->gather_level >= 0 && h->gather_level == level;
+    if (R->rows != coarse->n || R->cols != (gather ? h->gather_nglobal : fine->n)) return fail(MMG_ERR_INVALID, "restrict: shape mismatch");
     int rc = residual_dev(fine, false);
     if (rc) return rc;
-    if ((rc = exchange_vec(fine, fine->r.p))) return rc;  // K6: fine-residual halo
+    const double *rin = fine->r.p;
+    if (gather) {
+        // the coarse level is a complete copy on every rank: its right-hand side needs the WHOLE fine residual.
+        // Owned entries (the first n_owned of r) -> padded send buffer -> ncclAllGather -> global numbering.
+        const int no = fine->distributed ? fine->n_owned : fine->n;
+        if (no > h->gather_max) return fail(MMG_ERR_INVALID, "restrict: more owned points than the registered gather size");
+        HIPC(launch_fill(h->gsend.p, h->gather_max, 0.0, g_stream));
+        HIPC(hipMemcpyAsync(h->gsend.p, fine->r.p, sizeof(double) * (size_t)no, hipMemcpyDeviceToDevice, g_stream));
+        if (g_rccl.comm && g_rccl.nranks > 1) {
+            if (g_rccl.nranks != h->gather_ranks) return fail(MMG_ERR_COMM, "restrict: communicator size differs from the registered gather");
+            NCCLC(g_rccl.AllGather(h->gsend.p, h->grecv.p, (size_t)h->gather_max, kNcclDouble, g_rccl.comm, g_stream));
+        } else {
+            if (h->gather_ranks != 1) return fail(MMG_ERR_COMM, "restrict: gather over several ranks needs mmg_comm_init");
+            HIPC(hipMemcpyAsync(h->grecv.p, h->gsend.p, sizeof(double) * (size_t)h->gather_max, hipMemcpyDeviceToDevice, g_stream));
+        }
+        HIPC(launch_scatter_vals_masked(h->gvec.p, h->gather_gid.p, h->grecv.p, h->gather_ranks * h->gather_max, g_stream));
+        rin = h->gvec.p;
+    } else if ((rc = exchange_vec(fine, fine->r.p))) return rc;  // K6: fine-residual halo
     TileArgs a{};
     a.p = R->all.dev;
     a.n_list = R->all.n_tiles;
-    a.in = fine->r.p;
+    a.in = rin;
     a.out = coarse->b.p;
     HIPC(run_tiles(R->all, MODE_SET, a, g_stream));
     HIPC(launch_scatter_const(coarse->b.p, coarse->dir_idx.p, (int)coarse->dir_idx.n, 0.0, g_stream));
@@ -813,7 +839,7 @@ int cycle_body(mmg_hierarchy *h)
         if (i != nl - 1) HIPC(launch_fill(curr->x.p, curr->a_size, 0.0, g_stream));
         if ((rc = boundary_op(curr, i != nl - 1))) return rc;
         if ((rc = sweeps(curr, curr->iters))) return rc;
-        if ((rc = do_restrict(curr, h->lv[i - 1], h->R[i]))) return rc;
+        if ((rc = do_restrict(curr, h->lv[i - 1], h->R[i], h, i))) return rc;
     }
     if ((rc = boundary_op(curr, 1))) return rc;  // :91 (quirk N6: still the last loop grid)
     curr = h->lv[0];
@@ -846,6 +872,7 @@ int run_cycle_body(mmg_hierarchy *h)
 {
     bool eligible = g_graph != 0 && !h->graph_failed && g_sweep_events == nullptr;
     for (mmg_level *l : h->lv) eligible = eligible && !l->distributed;
+    eligible = eligible && h->gather_level < 0;
     if (!eligible || h->plain_runs < 1) {
         ++h->plain_runs;
         return run_cycle_body_plain(h);
@@ -1632,6 +1659,36 @@ int mmg_hierarchy_create(mmg_hierarchy **out, mmg_level **levels, int nlevels, m
     return MMG_OK;
 }
 void mmg_hierarchy_destroy(mmg_hierarchy *h) { delete h; }
+
+int mmg_hierarchy_set_gather(mmg_hierarchy *h, int level, int nranks, int max_count, const int *gid_all, int n_global)
+{
+    if (!h || level < 1 || level >= (int)h->lv.size() || nranks < 1 || max_count < 1 || !gid_all || n_global < 1)
+        return fail(MMG_ERR_INVALID, "hierarchy_set_gather: bad argument");
+    if (h->R[(size_t)level]->cols != n_global) return fail(MMG_ERR_INVALID, "hierarchy_set_gather: the restriction into the replicated level must have one column per GLOBAL fine point");
+    std::vector<uint8_t> seen((size_t)n_global, 0);
+    long long cnt = 0;
+    for (long long k = 0; k < (long long)nranks * max_count; ++k) {
+        const int g = gid_all[k];
+        if (g < -1 || g >= n_global) return fail(MMG_ERR_INVALID, "hierarchy_set_gather: global index out of range");
+        if (g >= 0) {
+            if (seen[(size_t)g]) return fail(MMG_ERR_INVALID, "hierarchy_set_gather: a fine point is owned twice");
+            seen[(size_t)g] = 1;
+            ++cnt;
+        }
+    }
+    if (cnt != n_global) return fail(MMG_ERR_INVALID, "hierarchy_set_gather: the ranks' owned points do not cover the level");
+    if (int rc = settle_hierarchy(h)) return rc;
+    ++g_state_gen;
+    HIPC(h->gather_gid.upload(gid_all, (size_t)nranks * (size_t)max_count));
+    HIPC(h->gsend.alloc((size_t)max_count));
+    HIPC(h->grecv.alloc((size_t)nranks * (size_t)max_count));
+    HIPC(h->gvec.alloc((size_t)n_global));
+    h->gather_level = level;
+    h->gather_ranks = nranks;
+    h->gather_max = max_count;
+    h->gather_nglobal = n_global;
+    return MMG_OK;
+}
 
 int mmg_vcycle(mmg_hierarchy *h, double *resid_before)
 {

@@ -738,6 +738,11 @@ __global__ void k_scatter_vals(double *v, const int32_t *idx, const double *vals
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[idx[i]] = vals[i];
 }
+__global__ void k_scatter_vals_masked(double *v, const int32_t *idx, const double *vals, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= 0) v[idx[i]] = vals[i];
+}
 
 // deterministic single-block sum of an array (fixed strides, fixed tree)
 __device__ double block_sum_256(const double *v, int n, double *sh)
@@ -1209,6 +1214,12 @@ hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_vals, dim3((n + 255) / 256), dim3(256), 0, s, v, idx, vals, n);
+    return hipGetLastError();
+}
+hipError_t launch_scatter_vals_masked(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scatter_vals_masked, dim3((n + 255) / 256), dim3(256), 0, s, v, idx, vals, n);
     return hipGetLastError();
 }
 hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial, double omega,

@@ -97,6 +97,7 @@ hipError_t launch_fill(double *v, long long n, double c, hipStream_t s);
 hipError_t launch_gather(double *dst, const double *src, const int32_t *idx, int n, hipStream_t s);
 hipError_t launch_scatter_const(double *v, const int32_t *idx, int n, double c, hipStream_t s);
 hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);
+hipError_t launch_scatter_vals_masked(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);  // idx < 0: skipped
 // x[n] <- (1-w) x[n] + w (b[n] - sum(partial))            (grid.cpp:118-141, row N)
 hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial,
                               double omega, hipStream_t s);

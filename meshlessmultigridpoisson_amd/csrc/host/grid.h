@@ -125,6 +125,7 @@ public:
     // by owner).  Filled by Multigrid::extract_subdomain; registered with the device by setup_exchange().
     struct ExchangeLists { vector<int> nbr, send_ptr, send_idx, recv_ptr; bool valid = false; } exchange_;
     void setup_exchange(bool per_phase = false);  // needs mmg_comm_init
+    bool replicated_ = false;  // a complete copy of a coarse level kept on every rank (Multigrid::extract_subdomain): no exchange
 
     vector<Point> pointIDs_to_vector(const vector<int> &pointIDs);
     vector<int> kNearestNeighbors(Point point, bool neumannFlag, bool pointBCFlag, int k);  // grid.cpp:216-260

@@ -493,6 +493,24 @@ void *mmgh_mg_extract_subdomain(void *h, int nparts, int rank)
     if (guard([&]() { out = static_cast<Multigrid *>(h)->extract_subdomain(nparts, rank, nullptr); })) return nullptr;
     return out;
 }
+// the same with coarse levels of at most `replicate_below` points kept complete on every rank
+void *mmgh_mg_extract_subdomain_replicated(void *h, int nparts, int rank, int replicate_below)
+{
+    Multigrid *out = nullptr;
+    if (guard([&]() { out = static_cast<Multigrid *>(h)->extract_subdomain(nparts, rank, nullptr, replicate_below); })) return nullptr;
+    return out;
+}
+// out4 = gather level (-1 none), ranks, max count, global points; gid (may be NULL) [ranks * max count]
+void mmgh_mg_gather_info(void *h, int *out4, int *gid)
+{
+    Multigrid *mg = static_cast<Multigrid *>(h);
+    out4[0] = mg->gatherLevel_;
+    out4[1] = mg->gatherRanks_;
+    out4[2] = mg->gatherMax_;
+    out4[3] = mg->gatherNGlobal_;
+    if (gid) std::memcpy(gid, mg->gatherGid_.data(), sizeof(int) * mg->gatherGid_.size());
+}
+int mmgh_grid_is_replicated(void *gp) { return static_cast<Grid *>(gp)->replicated_ ? 1 : 0; }
 // exchange lists Multigrid::extract_subdomain worked out for level l (sizes first: out4 = n_nbr, n_send;
 // then the arrays when non-NULL)
 int mmgh_grid_exchange_lists(void *gp, int *out2, int *nbr, int *send_ptr, int *send_idx, int *recv_ptr)

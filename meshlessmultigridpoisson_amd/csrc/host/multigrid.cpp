@@ -185,13 +185,19 @@ void Multigrid::vCycles(int n, float *device_ms)
         if (r >= 0) residuals_.push_back(r);
 }
 
-Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out)
+Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out, int replicate_below)
 {
     const size_t nl = grids_.size();
     if (nl > 1 && (restrictionMatrices_.size() != nl || prolongMatrices_.size() != nl))
         throw std::runtime_error("Multigrid::extract_subdomain: buildMatrices() first");
+    // levels 0 .. l_agg-1 stay complete on every rank (from this rank's point of view it owns all their points)
+    size_t l_agg = 0;
+    while (replicate_below > 0 && l_agg + 1 < nl && grids_[l_agg].second->getSize() <= replicate_below) ++l_agg;
     vector<vector<int>> part(nl);
-    for (size_t l = 0; l < nl; ++l) part[l] = grids_[l].second->partition_slabs(nparts);
+    for (size_t l = 0; l < nl; ++l) {
+        if (l < l_agg) part[l].assign((size_t)grids_[l].second->getSize(), rank);
+        else part[l] = grids_[l].second->partition_slabs(nparts);
+    }
     // ghost needs of the transfers: columns (points of the INPUT level) touched by owned rows
     auto need = [&](SparseColMajor *m, const vector<int> &row_part, int q, vector<int> &dst) {
         if (!m) return;
@@ -203,7 +209,8 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     };
     auto extras_of = [&](int q) {
         vector<vector<int>> ex(nl);
-        for (size_t l = 1; l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], q, ex[l]);  // R_l : level l -> l-1
+        // (R into a replicated level reads the all-gathered residual, not ghosts)
+        for (size_t l = std::max<size_t>(1, l_agg + 1); l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], q, ex[l]);  // R_l : level l -> l-1
         for (size_t l = 0; l + 1 < nl; ++l) need(prolongMatrices_[l], part[l + 1], q, ex[l]);  // P_l : level l -> l+1
         return ex;
     };
@@ -213,11 +220,13 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     vector<vector<int>> loc(nl);
     for (size_t l = 0; l < nl; ++l) {
         Grid *g = grids_[l].second->extract_subdomain(part[l], rank, &extra[l]);
+        g->replicated_ = l < l_agg;
         out->grids_.push_back(std::pair<int, Grid *>((int)l, g));  // keep the level order (sizes may tie)
         loc[l].assign((size_t)grids_[l].second->getSize(), -1);
         for (size_t k = 0; k < g->origIndex_.size(); ++k) loc[l][(size_t)g->origIndex_[k]] = (int)k;
     }
-    auto local_matrix = [&](SparseColMajor *m, size_t lrow, size_t lcol) -> SparseColMajor * {
+    // global_cols: the columns keep the GLOBAL numbering of level lcol (restriction into a replicated level)
+    auto local_matrix = [&](SparseColMajor *m, size_t lrow, size_t lcol, bool global_cols = false) -> SparseColMajor * {
         if (!m) return nullptr;
         vector<Triplet> trip;
         const int *cp = m->outerIndexPtr();
@@ -225,14 +234,32 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
         const double *v = m->valuePtr();
         for (int j = 0; j < m->cols(); ++j)
             for (int p = cp[j]; p < cp[j + 1]; ++p)
-                if (part[lrow][(size_t)ri[p]] == rank) trip.emplace_back(loc[lrow][(size_t)ri[p]], loc[lcol][(size_t)j], v[p]);
-        SparseColMajor *r = new SparseColMajor(out->grids_[lrow].second->getSize(), out->grids_[lcol].second->getSize(), false);
+                if (part[lrow][(size_t)ri[p]] == rank)
+                    trip.emplace_back(loc[lrow][(size_t)ri[p]], global_cols ? j : loc[lcol][(size_t)j], v[p]);
+        SparseColMajor *r = new SparseColMajor(out->grids_[lrow].second->getSize(),
+                                               global_cols ? m->cols() : out->grids_[lcol].second->getSize(), false);
         r->setFromTriplets(trip.begin(), trip.end());
         return r;
     };
     out->restrictionMatrices_.assign(nl, nullptr);
     out->prolongMatrices_.assign(nl, nullptr);
-    for (size_t l = 1; l < nl; ++l) out->restrictionMatrices_[l] = local_matrix(restrictionMatrices_[l], l - 1, l);
+    for (size_t l = 1; l < nl; ++l) out->restrictionMatrices_[l] = local_matrix(restrictionMatrices_[l], l - 1, l, l_agg > 0 && l == l_agg);
+    if (l_agg > 0) {
+        // who owns what of the coarsest decomposed level, in every rank's LOCAL order (Grid::extract_subdomain keeps
+        // the owned points in ascending global order): known to every rank without communication
+        const vector<int> &pa = part[l_agg];
+        vector<vector<int>> owned((size_t)nparts);
+        for (size_t i = 0; i < pa.size(); ++i) owned[(size_t)pa[i]].push_back((int)i);
+        size_t mx = 1;
+        for (auto &o : owned) mx = std::max(mx, o.size());
+        out->gatherLevel_ = (int)l_agg;
+        out->gatherRanks_ = nparts;
+        out->gatherMax_ = (int)mx;
+        out->gatherNGlobal_ = (int)pa.size();
+        out->gatherGid_.assign((size_t)nparts * mx, -1);
+        for (int q = 0; q < nparts; ++q)
+            for (size_t k = 0; k < owned[(size_t)q].size(); ++k) out->gatherGid_[(size_t)q * mx + k] = owned[(size_t)q][k];
+    }
     for (size_t l = 0; l + 1 < nl; ++l) out->prolongMatrices_[l] = local_matrix(prolongMatrices_[l], l + 1, l);
     // Exchange lists: the global hierarchy is known to every rank, so what a neighbour q needs from this rank
     // is q's ghost list restricted to this rank's points -- no communication (the Python harness gathers the
@@ -270,7 +297,13 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
 
 void Multigrid::setup_exchange(bool per_phase)
 {
-    for (auto &g : grids_) g.second->setup_exchange(per_phase);
+    for (auto &g : grids_)
+        if (!g.second->replicated_) g.second->setup_exchange(per_phase);  // replicated levels: no exchange at all
+    if (gatherLevel_ >= 0) {
+        ensure_device();
+        dev_check(mmg_hierarchy_set_gather(devH_, gatherLevel_, gatherRanks_, gatherMax_, gatherGid_.data(), gatherNGlobal_),
+                  "mmg_hierarchy_set_gather");
+    }
 }
 
 double Multigrid::residual()

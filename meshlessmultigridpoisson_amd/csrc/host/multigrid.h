@@ -41,7 +41,14 @@ public:
     // `nparts` x-slabs; the result holds rank's sub-domain of every level (ghosts cover the level
     // operator AND the columns the local rows of R / P touch) and the local rows of the transfer
     // matrices.  parts_out[l] receives the owner of every global point of level l.
-    Multigrid *extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out = nullptr);
+    // replicate_below > 0: levels of at most that many points are NOT cut but kept complete on every rank
+    // ("agglomeration" by replication): they are relaxed without communication; the restriction into
+    // the finest of them reads the all-gathered residual of the coarsest decomposed level (gather_*_ below,
+    // registered by setup_exchange through mmg_hierarchy_set_gather).  The finest level is always decomposed.
+    Multigrid *extract_subdomain(int nparts, int rank, vector<vector<int>> *parts_out = nullptr, int replicate_below = 0);
+    int gatherLevel_ = -1;            // coarsest decomposed level (-1: every level is decomposed)
+    int gatherRanks_ = 0, gatherMax_ = 0, gatherNGlobal_ = 0;
+    vector<int> gatherGid_;           // [gatherRanks_ * gatherMax_], -1 padded
     // Multi-GPU run of a hierarchy returned by extract_subdomain (one process per GPU, mmg_comm_init done):
     // registers every level's ghost exchange with the device -- the lists were worked out at extraction, from the
     // global hierarchy every rank holds, without communication.  per_phase: exact mode (mmg_level_set_exchange_mode).

@@ -247,6 +247,8 @@ class _Rank:
             self.R[l] = sub.transfer("R", l)
             self.P[l] = sub.transfer("P", l)
         self.lists = None
+        self.repl = {l for l in range(self.nl) if sub.grid(l).is_replicated()}  # complete copies: no exchange
+        self.gather = sub.gather_info()
 
     def dir_idx(self, l):
         la = self.la[l]
@@ -273,6 +275,10 @@ def _exchange(ranks, l, get, put):
 
 
 def _dist_sweeps(ranks, l, k, exact=False):
+    if l in ranks[0].repl:   # replicated level: every rank relaxes its complete copy, nothing is exchanged or reduced
+        for rk in ranks:
+            rk.lv[l].sweeps(k)
+        return
     neumann = ranks[0].la[l]["neumann"]
     n = [rk.la[l]["n"] for rk in ranks]
     gmax = max(rk.lv[l].info()["n_phases"] for rk in ranks)
@@ -299,6 +305,10 @@ def _dist_sweeps(ranks, l, k, exact=False):
 
 def _dist_residual(ranks, l):
     """Returns per-rank r vectors (ghost entries refreshed) and the all-reduced ratio."""
+    if l in ranks[0].repl:
+        for rk in ranks:
+            rk._r, _ = rk.lv[l].residual()
+        return None
     neumann = ranks[0].la[l]["neumann"]
     _exchange(ranks, l, lambda rk: rk.lv[l].x, lambda rk: rk.lv[l].x)
     rs, nr, nb = [], 0.0, 0.0
@@ -335,10 +345,21 @@ def _dist_vcycle(ranks, exact=False):
             e.x[rk.dir_idx(i)] = 0.0 if i != nl - 1 else rk.la[i]["bvals"][: len(rk.dir_idx(i))]
         _dist_sweeps(ranks, i, ranks[0].la[i]["iters"], exact)
         _dist_residual(ranks, i)
+        gathered = None
+        if ranks[0].gather is not None and ranks[0].gather[0] == i:
+            # mmg_hierarchy_set_gather: restriction into a replicated level reads the all-gathered residual
+            _lvl, nr_, mx, ng, gid = ranks[0].gather
+            gathered = np.zeros(ng)
+            for q, rk in enumerate(ranks):
+                no = rk.maps[i][0]
+                assert np.array_equal(gid[q, :no], rk.maps[i][1][:no]) and np.all(gid[q, no:] == -1)
+                gathered[gid[q, :no]] = rk._r[:no]
         for rk in ranks:
             R = rk.R[i]
             nf, nc = rk.la[i]["n"], rk.la[i - 1]["n"]
-            bc = H.emu_transfer_apply((R["rows"], R["cols"]), R["colptr"], R["rowidx"], R["val"], rk._r[:nf])
+            rin = gathered if gathered is not None else rk._r[:nf]
+            assert R["cols"] == len(rin)
+            bc = H.emu_transfer_apply((R["rows"], R["cols"]), R["colptr"], R["rowidx"], R["val"], rin)
             ec = rk.lv[i - 1]
             ec.b[:nc] = bc
             ec.b[rk.dir_idx(i - 1)] = 0.0
@@ -404,6 +425,54 @@ def test_distributed_vcycle_matches_hybrid_oracle(neumann):
     if neumann:
         x[-1] = ranks[0].lv[-1].x[-1]
     assert np.abs(x - om.levels[-1].x).max() <= 1e-10 * np.abs(om.levels[-1].x).max()
+
+
+@pytest.mark.parametrize("neumann", [False, True])
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_distributed_vcycle_with_replicated_coarse_levels(neumann, nparts):
+    """Multigrid::extract_subdomain(..., replicate_below): the two coarse levels stay complete on every rank
+    (relaxed sequentially, no exchange, no all-reduce), only the finest level is decomposed; the restriction into
+    the replicated level reads the ALL-GATHERED fine residual (mmg_hierarchy_set_gather), the prolongation out of it
+    needs no exchange.  Oracle: orc_vcycle_hybrid with a single part on the replicated levels."""
+    from meshlessmultigridpoisson_amd import _host as host
+    clouds = [host.square_cloud(n, seed=300 + i) for i, n in enumerate([13, 25, 41])]
+    mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
+    om = H.oracle_of_multigrid(mg)
+    n1 = mg.grid(1).sizes()["n"]
+    parts = [np.zeros(mg.grid(0).sizes()["n"], dtype=np.int32), np.zeros(n1, dtype=np.int32), mg.level_part(2, nparts)]
+    subs = [mg.extract_subdomain(nparts, r, replicate_below=n1) for r in range(nparts)]
+    for r, sub in enumerate(subs):
+        assert [sub.grid(l).is_replicated() for l in range(3)] == [True, True, False]
+        lvl, nr_, mx, ng, gid = sub.gather_info()
+        assert (lvl, nr_, ng) == (2, nparts, mg.grid(2).sizes()["n"])
+        for q in range(nparts):
+            assert np.array_equal(gid[q][gid[q] >= 0], np.flatnonzero(parts[2] == q))
+        assert sub.transfer("R", 2)["cols"] == ng and sub.transfer("P", 1)["cols"] == n1
+    ranks = [_Rank(host, s, r) for r, s in enumerate(subs)]
+    for l in range(mg.nlevels):
+        needs = [{int(o): rk.maps[l][1][rk.maps[l][0]:][rk.maps[l][2] == o] for o in np.unique(rk.maps[l][2])} for rk in ranks]
+        for r, rk in enumerate(ranks):
+            no, gid_l, gown = rk.maps[l]
+            lst = host.build_exchange_lists(r, no, gid_l, gown, lambda obj: needs)
+            if rk.lists is None:
+                rk.lists = []
+            rk.lists.append(lst)
+            if l < 2:
+                assert len(lst[0]) == 0 and no == rk.la[l]["n"]       # nothing to exchange on a replicated level
+    for k in range(4):
+        ro = om.vcycle_hybrid(parts, nparts)
+        rd = _dist_vcycle(ranks)
+        assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
+    x = np.zeros_like(om.levels[-1].x)
+    for rk in ranks:
+        no, gid_l, _ = rk.maps[-1]
+        x[gid_l[:no]] = rk.lv[-1].x[:no]
+    if neumann:
+        x[-1] = ranks[0].lv[-1].x[-1]
+    assert np.abs(x - om.levels[-1].x).max() <= 1e-10 * np.abs(om.levels[-1].x).max()
+    for l in (0, 1):                                               # the copies stay identical
+        for rk in ranks[1:]:
+            assert np.array_equal(rk.lv[l].x, ranks[0].lv[l].x)
 
 
 def _phase_conflicts(ranks, l):

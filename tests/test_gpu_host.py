@@ -198,3 +198,31 @@ def test_cpp_setup_exchange_single_rank_hierarchy(host, neumann):
             assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
     finally:
         _capi.comm_finalize()
+
+
+@pytest.mark.parametrize("neumann", [False, True])
+def test_cpp_replicated_coarse_levels_single_rank(host, neumann):
+    """Multigrid::extract_subdomain(1, 0, replicate_below): the coarse levels are marked as complete copies
+    (no exchange lists, no all-reduce), the restriction into the first of them goes through the gather path of
+    mmg_hierarchy_set_gather (pad, gather, scatter by global index, R with global columns).  One rank: the gather
+    is a device copy, the V-cycle must follow the oracle of the undecomposed hierarchy.  (2 and 3 ranks: CPU
+    emulation, tests/test_distributed_cpu.py.)"""
+    from meshlessmultigridpoisson_amd import _capi
+    clouds = [host.square_cloud(n, seed=177 + i) for i, n in enumerate([13, 25, 41])]
+    mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
+    om = H.oracle_of_multigrid(mg)
+    n1 = mg.grid(1).sizes()["n"]
+    sub = mg.extract_subdomain(1, 0, replicate_below=n1)
+    assert [sub.grid(l).is_replicated() for l in range(3)] == [True, True, False]
+    lvl, nr_, mx, ng, gid = sub.gather_info()
+    assert (lvl, nr_, mx, ng) == (2, 1, mg.grid(2).sizes()["n"], mg.grid(2).sizes()["n"])
+    assert np.array_equal(gid[0], np.arange(ng))
+    _capi.comm_init(0, 1, _capi.comm_unique_id())
+    try:
+        sub.setup_exchange_native(exact=False)
+        for k in range(6):
+            ro, rd = om.vcycle(), sub.vcycle()
+            assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+        assert H.rel_err(sub.grid(2).values(), om.levels[-1].x) < 1e-10
+    finally:
+        _capi.comm_finalize()
