@@ -273,6 +273,28 @@ int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cl
                     long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
                     double *weights);
 
+/* Neighbour search + weights in one call: mmg_knn's lists (stencil = k; cloud_flag / eval_flag as there, may be
+ * NULL) feed mmg_rbf_weights without leaving the device; nbr [n_eval][stencil] (may be NULL) receives them.
+ * by_column != 0: every row (ids and weights alike) comes back in ascending order of the neighbour id -- the
+ * order of a CSR row (Eigen's setFromTriplets) -- instead of nearest first.
+ * *short_rows = number of evaluation points for which the cloud held fewer than `stencil` candidates; when it is
+ * not 0 no weights have been produced (the caller decides what a short stencil means). */
+int mmg_rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                     const unsigned char *cloud_flag, long long n_eval, const double *eval_xyz, const unsigned char *eval_flag,
+                     int n_ops, const int *ops, int by_column, int *nbr, double *weights, int *short_rows);
+
+/* ---- setup: k nearest neighbours ----------------------------------------------------------
+ * Grid::kNearestNeighbors (grid.cpp:216-260) for many query points at once: nbr[e][0..k) = the indices of the
+ * k smallest (distance, index) pairs of query e over the cloud, ascending (distance = sqrt(dx*dx + dy*dy
+ * [+ dz*dz]) evaluated in that order, as the reference's `distance`).  For a query with query_flag != 0 the
+ * candidates with cloud_flag != 0 are skipped unless their distance is exactly 0 (a Neumann grid's boundary
+ * point ignores the other boundary points, grid.cpp:224,236,244); both flag arrays may be NULL.  -1 fills the
+ * tail of a row when the cloud holds fewer than k candidates.  k <= 256.  Uniform cell grid + one wavefront
+ * per query on the MI355X instead of the reference's scan of the whole cloud per query.
+ *   cloud_xyz [n_cloud][3], query_xyz [n_query][3] (z ignored when dim == 2), nbr [n_query][k] */
+int mmg_knn(int dim, int n_cloud, const double *cloud_xyz, const unsigned char *cloud_flag, long long n_query,
+            const double *query_xyz, const unsigned char *query_flag, int k, int *nbr);
+
 /* ---- fractional-step grid == FractionalStepGrid (fractionalStepGrid.hpp) -------------------
  * Velocity predictor, pressure-Poisson source and corrector around the pressure level `p`
  * (whose values_/source_ are the pressure and the PPE right-hand side).  u, v, u_hat, v_hat

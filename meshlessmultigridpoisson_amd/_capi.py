@@ -53,6 +53,8 @@ SYMBOLS = [
     "mmg_fracstep_correct", "mmg_fracstep_residual", "mmg_fracstep_create_3d", "mmg_fracstep_set_bound_values",
     "mmg_fracstep_apply_bound", "mmg_fracstep_step", "mmg_level_set_neumann_coupling", "mmg_level_push_inhomog_to_rhs",
     "mmg_hierarchy_set_gather",
+    "mmg_knn",
+    "mmg_rbf_stencils",
 ]
 
 _lib = None
@@ -181,6 +183,23 @@ def rbf_weights(dim, polydeg, rbf_exp, cloud_xyz, eval_xyz, nbr, ops):
     f.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _dp, C.c_longlong, _dp, _ip, C.c_int, _ip, _dp]
     check(f(dim, polydeg, float(rbf_exp), nb.shape[1], cloud.shape[0], cloud.ctypes.data_as(_dp), ev.shape[0],
             ev.ctypes.data_as(_dp), nb.ctypes.data_as(_ip), len(op), op.ctypes.data_as(_ip), out.ctypes.data_as(_dp)))
+    return out
+
+
+def knn(dim, cloud_xyz, query_xyz, k, cloud_flag=None, query_flag=None):
+    """mmg_knn: indices of the k smallest (distance, index) pairs per query, [n_query][k] (-1 = cloud ran out)."""
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float64).reshape(-1, 3)
+    q = np.ascontiguousarray(query_xyz, dtype=np.float64).reshape(-1, 3)
+    cf = None if cloud_flag is None else np.ascontiguousarray(cloud_flag, dtype=np.uint8)
+    qf = None if query_flag is None else np.ascontiguousarray(query_flag, dtype=np.uint8)
+    assert cf is None or len(cf) == len(cloud)
+    assert qf is None or len(qf) == len(q)
+    out = np.zeros((q.shape[0], int(k)), dtype=np.int32)
+    f = lib().mmg_knn
+    _bp = C.POINTER(C.c_ubyte)
+    f.argtypes = [C.c_int, C.c_int, _dp, _bp, C.c_longlong, _dp, _bp, C.c_int, _ip]
+    check(f(dim, cloud.shape[0], cloud.ctypes.data_as(_dp), cf.ctypes.data_as(_bp) if cf is not None else None, q.shape[0],
+            q.ctypes.data_as(_dp), qf.ctypes.data_as(_bp) if qf is not None else None, int(k), out.ctypes.data_as(_ip)))
     return out
 
 

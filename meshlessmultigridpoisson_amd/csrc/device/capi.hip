@@ -14,6 +14,7 @@
 #include "../../../include/mmgp.h"
 #include "kernels.hpp"
 #include "rbf_setup.hpp"
+#include "knn_dev.hpp"
 #include "level_plan.hpp"
 #include "plan.hpp"
 
@@ -1207,10 +1208,13 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
         }
         if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8 || waves == 12))
             return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4, 6, 8 or 12");
+        std::unique_ptr<StageTimer> st(new StageTimer("level_create: build_level_plan"));
         const std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
         lv->A.exact = g_exact;
+        st.reset(new StageTimer("level_create: upload"));
         if ((rc = lv->A.upload(P))) return rc;
+        st.reset(new StageTimer("level_create: point phases"));
         if (!level_point_phases(*d, P, &lv->point_phase, &lv->ghost_mask).empty()) {
             lv->point_phase.clear();  // exact exchange mode unavailable, the once-per-sweep mode still is
             lv->ghost_mask.clear();
@@ -1762,21 +1766,156 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny)
     return MMG_OK;
 }
 
+// ---- setup: k nearest neighbours (knn.hip) ------------------------------------------------
+namespace {
+struct KnnIndex {
+    KnnCells cells{};
+    DevBuf<int> cell_ptr, id;
+    DevBuf<double> x, y, z;
+    DevBuf<unsigned char> flag;
+    int r0 = 2;
+
+    // cell grid over the cloud (h_xyz: host copy for the bounding box, d_xyz: the same on the device)
+    int build(int dim, int n, const double *h_xyz, const double *d_xyz, const unsigned char *h_flag, int k)
+    {
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int a = 0; a < dim; ++a) lo[a] = hi[a] = h_xyz[a];
+        for (size_t i = 0; i < (size_t)n; ++i)
+            for (int a = 0; a < dim; ++a) {
+                lo[a] = std::min(lo[a], h_xyz[3 * i + a]);
+                hi[a] = std::max(hi[a], h_xyz[3 * i + a]);
+            }
+        // With the first block (r0 = 2: 5 cells per axis) accepted when the k-th distance stays below 2 cells,
+        // k/20 points per cell in 3-D (k/9 in 2-D) puts the k-th neighbour at about 1.7 cells.
+        const double ppc = std::max(1.0, dim >= 3 ? k / 20.0 : k / 9.0);
+        double vol = 1.0;
+        for (int a = 0; a < dim; ++a) vol *= std::max(hi[a] - lo[a], 1e-300);
+        double cs = std::pow(vol * ppc / (double)n, 1.0 / dim);
+        if (!(cs > 0) || !std::isfinite(cs)) cs = 1.0;
+        const double cap = std::max(64.0, 4.0 * (double)n);  // degenerate extents: never more than 4 cells per point
+        for (;;) {
+            double total = 1.0;
+            for (int a = 0; a < 3; ++a) {
+                const double m = a < dim ? std::floor((hi[a] - lo[a]) / cs) + 1.0 : 1.0;
+                total *= m;
+                cells.nc[a] = (int)std::min(m, 2.0e9);
+            }
+            if (total <= cap) break;
+            cs *= 1.26;
+        }
+        for (int a = 0; a < 3; ++a) cells.lo[a] = lo[a];
+        cells.cs = cs;
+        cells.dim = dim;
+        const size_t ncell = (size_t)cells.nc[0] * cells.nc[1] * cells.nc[2];
+        DevBuf<int> cell_of, count;
+        DevBuf<unsigned char> d_flag, tmp;
+        HIPC(cell_of.alloc((size_t)n));
+        HIPC(count.alloc(ncell + 1));
+        HIPC(cell_ptr.alloc(ncell + 1));
+        HIPC(hipMemsetAsync(count.p, 0, sizeof(int) * (ncell + 1), g_stream));
+        HIPC(launch_knn_count(cells, d_xyz, n, cell_of.p, count.p, g_stream));
+        size_t tmp_bytes = 0;
+        HIPC(knn_exclusive_scan(nullptr, &tmp_bytes, count.p, cell_ptr.p, (int)(ncell + 1), g_stream));
+        HIPC(tmp.alloc(tmp_bytes + 16));
+        HIPC(knn_exclusive_scan(tmp.p, &tmp_bytes, count.p, cell_ptr.p, (int)(ncell + 1), g_stream));
+        HIPC(hipMemsetAsync(count.p, 0, sizeof(int) * (ncell + 1), g_stream));
+        HIPC(x.alloc((size_t)n));
+        HIPC(y.alloc((size_t)n));
+        HIPC(z.alloc((size_t)n));
+        HIPC(id.alloc((size_t)n));
+        if (h_flag) {
+            HIPC(d_flag.upload(h_flag, (size_t)n));
+            HIPC(flag.alloc((size_t)n));
+        }
+        HIPC(launch_knn_fill(d_xyz, h_flag ? d_flag.p : nullptr, n, cell_of.p, cell_ptr.p, count.p, x.p, y.p, z.p, id.p,
+                             h_flag ? flag.p : nullptr, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+        cells.cell_ptr = cell_ptr.p;
+        cells.x = x.p;
+        cells.y = y.p;
+        cells.z = z.p;
+        cells.id = id.p;
+        cells.flag = h_flag ? flag.p : nullptr;
+        return MMG_OK;
+    }
+
+    // neighbours of ne queries already on the device
+    int search(const double *d_query, const unsigned char *d_qflag, long long ne, int k, int *d_out, int cus, int *d_short = nullptr)
+    {
+        KnnArgs a{};
+        a.c = cells;
+        a.query = d_query;
+        a.qflag = cells.flag ? d_qflag : nullptr;
+        a.n_query = ne;
+        a.k = k;
+        a.r0 = r0;
+        a.out = d_out;
+        a.short_rows = d_short;
+        HIPC(launch_knn(a, (int)std::min<long long>(ne, 128LL * cus), g_stream));
+        return MMG_OK;
+    }
+};
+}  // namespace
+
+int mmg_knn(int dim, int n_cloud, const double *cloud_xyz, const unsigned char *cloud_flag, long long n_query,
+            const double *query_xyz, const unsigned char *query_flag, int k, int *nbr)
+{
+    if (dim < 2 || dim > 3 || n_cloud < 1 || !cloud_xyz || n_query < 0 || !query_xyz || k < 1 || !nbr)
+        return fail(MMG_ERR_INVALID, "knn: bad argument");
+    if (k > kKnnMaxK) return fail(MMG_ERR_UNSUPPORTED, "knn: more than 256 neighbours per query");
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n_query == 0) return MMG_OK;
+    int cus = 0, lds_cu = 0;
+    if ((rc = mmg_device_props(&cus, &lds_cu))) return rc;
+    const bool flagged = cloud_flag != nullptr && query_flag != nullptr;
+    KnnIndex ix;
+    {
+        DevBuf<double> d_cloud;
+        HIPC(d_cloud.upload(cloud_xyz, (size_t)n_cloud * 3));
+        if ((rc = ix.build(dim, n_cloud, cloud_xyz, d_cloud.p, flagged ? cloud_flag : nullptr, k))) return rc;
+    }
+    const long long chunk = 1 << 21;
+    DevBuf<double> d_q;
+    DevBuf<unsigned char> d_qf;
+    DevBuf<int> d_out;
+    HIPC(d_q.alloc((size_t)std::min(n_query, chunk) * 3));
+    HIPC(d_out.alloc((size_t)std::min(n_query, chunk) * k));
+    if (flagged) HIPC(d_qf.alloc((size_t)std::min(n_query, chunk)));
+    for (long long e0 = 0; e0 < n_query; e0 += chunk) {
+        const long long ne = std::min(chunk, n_query - e0);
+        HIPC(hipMemcpyAsync(d_q.p, query_xyz + 3 * e0, sizeof(double) * 3 * (size_t)ne, hipMemcpyHostToDevice, g_stream));
+        if (flagged) HIPC(hipMemcpyAsync(d_qf.p, query_flag + e0, (size_t)ne, hipMemcpyHostToDevice, g_stream));
+        if ((rc = ix.search(d_q.p, d_qf.p, ne, k, d_out.p, cus))) return rc;
+        HIPC(hipMemcpyAsync(nbr + e0 * k, d_out.p, sizeof(int) * (size_t)ne * k, hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+    }
+    return MMG_OK;
+}
+
 // ---- setup: batched RBF-FD stencil weights (rbf_setup.hip) ------------------------------
-int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
-                    long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
-                    double *weights)
+namespace {
+// nbr_in != nullptr: the caller's neighbour lists; nullptr: searched on the device (mmg_knn's rules), written to
+// nbr_out when that is not nullptr.
+int rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                 const unsigned char *cloud_flag, long long n_eval, const double *eval_xyz, const unsigned char *eval_flag,
+                 const int *nbr_in, int n_ops, const int *ops, int *nbr_out, double *weights, int *short_rows, int by_column = 0)
 {
     if (dim < 2 || dim > 3 || poly_deg < 0 || poly_deg > 8 || stencil < 1 || n_cloud < 1 || n_eval < 0 || !cloud_xyz ||
-        !eval_xyz || !nbr || n_ops < 1 || n_ops > 4 || !ops || !weights)
+        !eval_xyz || n_ops < 1 || n_ops > 4 || !ops || !weights)
         return fail(MMG_ERR_INVALID, "rbf_weights: bad argument");
     const int pt = dim >= 3 ? (poly_deg + 1) * (poly_deg + 2) * (poly_deg + 3) / 6 : (poly_deg + 1) * (poly_deg + 2) / 2;
     if (2 * stencil < pt) return fail(MMG_ERR_INVALID, "rbf_weights: stencil smaller than half the polynomial terms");
     for (int o = 0; o < n_ops; ++o)
         if (ops[o] < 0 || ops[o] > 4 || (ops[o] == RBF_OP_DZ && dim < 3)) return fail(MMG_ERR_INVALID, "rbf_weights: bad operator id");
-    // every neighbour id is dereferenced on the device: check them here, on the host
-    for (long long i = 0; i < n_eval * stencil; ++i)
-        if (nbr[i] < 0 || nbr[i] >= n_cloud) return fail(MMG_ERR_INVALID, "rbf_weights: neighbour id out of range");
+    if (nbr_in) {
+        // every neighbour id is dereferenced on the device: check them here, on the host
+        for (long long i = 0; i < n_eval * stencil; ++i)
+            if (nbr_in[i] < 0 || nbr_in[i] >= n_cloud) return fail(MMG_ERR_INVALID, "rbf_weights: neighbour id out of range");
+    } else if (stencil > kKnnMaxK) {
+        return fail(MMG_ERR_UNSUPPORTED, "rbf_stencils: more than 256 neighbours per stencil");
+    }
+    if (short_rows) *short_rows = 0;
     int rc = ensure_device();
     if (rc) return rc;
     if (n_eval == 0) return MMG_OK;
@@ -1786,18 +1925,41 @@ int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cl
     if ((rc = mmg_device_props(&cus, &lds_cu))) return rc;
     if (lds > (size_t)lds_cu) return fail(MMG_ERR_UNSUPPORTED, "rbf_weights: saddle system does not fit the LDS of one CU");
     DevBuf<double> d_cloud, d_eval, d_w;
-    DevBuf<int> d_nbr;
+    DevBuf<int> d_nbr, d_short;
+    DevBuf<unsigned char> d_qf;
     HIPC(d_cloud.upload(cloud_xyz, (size_t)n_cloud * 3));
+    KnnIndex ix;
+    const bool flagged = !nbr_in && cloud_flag != nullptr && eval_flag != nullptr;
+    if (!nbr_in) {
+        if ((rc = ix.build(dim, n_cloud, cloud_xyz, d_cloud.p, flagged ? cloud_flag : nullptr, stencil))) return rc;
+        HIPC(d_short.alloc(1));
+        HIPC(hipMemsetAsync(d_short.p, 0, sizeof(int), g_stream));
+    }
     // evaluation points in chunks: bounds the device footprint (nbr + weights: 12 B x stencil x n_ops per point)
     const long long chunk = 1 << 21;
     HIPC(d_eval.alloc((size_t)std::min(n_eval, chunk) * 3));
     HIPC(d_nbr.alloc((size_t)std::min(n_eval, chunk) * stencil));
     HIPC(d_w.alloc((size_t)std::min(n_eval, chunk) * stencil * n_ops));
+    if (flagged) HIPC(d_qf.alloc((size_t)std::min(n_eval, chunk)));
     const int resident = std::max(1, cus * std::max(1, (int)((size_t)lds_cu / lds)));
     for (long long e0 = 0; e0 < n_eval; e0 += chunk) {
         const long long ne = std::min(chunk, n_eval - e0);
         HIPC(hipMemcpyAsync(d_eval.p, eval_xyz + 3 * e0, sizeof(double) * 3 * (size_t)ne, hipMemcpyHostToDevice, g_stream));
-        HIPC(hipMemcpyAsync(d_nbr.p, nbr + e0 * stencil, sizeof(int) * (size_t)ne * stencil, hipMemcpyHostToDevice, g_stream));
+        if (nbr_in) {
+            HIPC(hipMemcpyAsync(d_nbr.p, nbr_in + e0 * stencil, sizeof(int) * (size_t)ne * stencil, hipMemcpyHostToDevice, g_stream));
+        } else {
+            if (flagged) HIPC(hipMemcpyAsync(d_qf.p, eval_flag + e0, (size_t)ne, hipMemcpyHostToDevice, g_stream));
+            if ((rc = ix.search(d_eval.p, d_qf.p, ne, stencil, d_nbr.p, cus, d_short.p))) return rc;
+            int n_short = 0;
+            HIPC(hipMemcpyAsync(&n_short, d_short.p, sizeof(int), hipMemcpyDeviceToHost, g_stream));
+            HIPC(hipStreamSynchronize(g_stream));
+            if (n_short > 0) {  // the cloud ran out of candidates: no weights (an id of -1 must not reach the solver)
+                if (short_rows) *short_rows = n_short;
+                return MMG_OK;
+            }
+            if (nbr_out && !by_column)
+                HIPC(hipMemcpyAsync(nbr_out + e0 * stencil, d_nbr.p, sizeof(int) * (size_t)ne * stencil, hipMemcpyDeviceToHost, g_stream));
+        }
         a.cloud = d_cloud.p;
         a.eval = d_eval.p;
         a.nbr = d_nbr.p;
@@ -1811,12 +1973,36 @@ int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cl
         for (int o = 0; o < n_ops; ++o) a.ops[o] = ops[o];
         a.rbf_exp = rbf_exp;
         HIPC(launch_rbf_weights(a, (int)std::min<long long>(ne, 2LL * resident), lds, g_stream));
+        if (by_column && !nbr_in) {
+            HIPC(launch_sort_rows(d_nbr.p, d_w.p, ne, stencil, n_ops, (int)std::min<long long>(ne, 128LL * cus), g_stream));
+            if (nbr_out)
+                HIPC(hipMemcpyAsync(nbr_out + e0 * stencil, d_nbr.p, sizeof(int) * (size_t)ne * stencil, hipMemcpyDeviceToHost, g_stream));
+        }
         for (int o = 0; o < n_ops; ++o)
             HIPC(hipMemcpyAsync(weights + ((size_t)o * n_eval + e0) * stencil, d_w.p + (size_t)o * ne * stencil,
                                 sizeof(double) * (size_t)ne * stencil, hipMemcpyDeviceToHost, g_stream));
         HIPC(hipStreamSynchronize(g_stream));
     }
     return MMG_OK;
+}
+}  // namespace
+
+int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                    long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
+                    double *weights)
+{
+    if (!nbr) return fail(MMG_ERR_INVALID, "rbf_weights: bad argument");
+    return rbf_stencils(dim, poly_deg, rbf_exp, stencil, n_cloud, cloud_xyz, nullptr, n_eval, eval_xyz, nullptr, nbr, n_ops, ops,
+                        nullptr, weights, nullptr);
+}
+
+int mmg_rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
+                     const unsigned char *cloud_flag, long long n_eval, const double *eval_xyz, const unsigned char *eval_flag,
+                     int n_ops, const int *ops, int by_column, int *nbr, double *weights, int *short_rows)
+{
+    if (!short_rows) return fail(MMG_ERR_INVALID, "rbf_stencils: bad argument");
+    return rbf_stencils(dim, poly_deg, rbf_exp, stencil, n_cloud, cloud_xyz, cloud_flag, n_eval, eval_xyz, eval_flag, nullptr, n_ops,
+                        ops, nbr, weights, short_rows, by_column);
 }
 
 // ---- fractional-step grid --------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <memory>
 #include <thread>
 
 namespace mmg {
@@ -119,6 +120,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         const int32_t gid = s.rows[r0 + k];
         uint16_t flags = 0;
         bool has_diag = false;
+        ent[k].reserve((size_t)(A.rowptr[gid + 1] - A.rowptr[gid]));
         for (int p = A.rowptr[gid]; p < A.rowptr[gid + 1]; ++p) {
             const int32_t col = A.col[p];
             const double v = A.val[p];
@@ -244,12 +246,20 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             tb.blob.resize(base + group_bytes(L, g, plen, s.slot_bits), 0);
             // 12-bit stream: slot q of a lane = bits [12q, 12q+12) of its words (word w at [w*W + lane])
             auto put12 = [&](uint8_t *Bp, size_t q, size_t lane, uint16_t v) {
-                for (int b = 0; b < 12; ++b) {
-                    const size_t bit = 12 * q + (size_t)b;
-                    uint8_t *byte = Bp + slots_off + ((bit / 64) * W + lane) * 8 + (bit % 64) / 8;
-                    const uint8_t m = (uint8_t)(1u << (bit % 8));
-                    if ((v >> b) & 1) *byte |= m;
-                    else *byte &= (uint8_t)~m;
+                const size_t bit = 12 * q, wi = bit / 64;
+                const unsigned sh = (unsigned)(bit % 64);
+                const uint64_t val = (uint64_t)(v & 0xFFFu);
+                uint8_t *p = Bp + slots_off + (wi * W + lane) * 8;  // little-endian words: bit b of a word = byte b/8, bit b%8
+                uint64_t word;
+                std::memcpy(&word, p, 8);
+                word = (word & ~((uint64_t)0xFFFu << sh)) | (val << sh);
+                std::memcpy(p, &word, 8);
+                if (sh > 52) {  // the slot straddles two words
+                    const unsigned done = 64 - sh;
+                    p = Bp + slots_off + ((wi + 1) * W + lane) * 8;
+                    std::memcpy(&word, p, 8);
+                    word = (word & ~((uint64_t)0xFFFu >> done)) | (val >> done);
+                    std::memcpy(p, &word, 8);
                 }
             };
             uint8_t *B = tb.blob.data();
@@ -329,6 +339,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     for (int64_t k = 0; k < s.n_rows; ++k)
         if (s.rows[k] < 0 || s.rows[k] >= A.rows) return "row id outside the matrix";
 
+    std::unique_ptr<StageTimer> st(new StageTimer("build_plan: tiles"));
     std::vector<TileBuild> tb(s.n_tiles);
     // host threads of the plan packer: PlanSpec::n_threads, else MMG_NUM_THREADS, else all hardware threads
     // (one process per GPU on an 8-GPU node: the launcher gives every rank its share, see bench.py)
@@ -359,6 +370,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         if (!tb[t].err.empty()) return tb[t].err;
 
     // ---- assemble ------------------------------------------------------------
+    st.reset(new StageTimer("build_plan: assemble"));
     Plan &P = *out;
     P = Plan();
     P.L = L;
@@ -419,6 +431,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     }
 
     // ---- phases --------------------------------------------------------------
+    st.reset(new StageTimer("build_plan: phases"));
     std::vector<int32_t> phase(s.n_tiles, 0);
     int n_phases = 1;
     if (s.in_place) {

@@ -41,11 +41,28 @@
 //     (8, 12 or 16 B: one load).  dense_val_off() / dense_slot_off() below are THE definition.
 //     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
 
 namespace mmg {
+
+// wall-clock stamps of the setup stages on stderr when MMG_VERBOSE is set (development aid)
+struct StageTimer {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer()
+    {
+        if (std::getenv("MMG_VERBOSE"))
+            std::fprintf(stderr, "[setup]   %-36s %8.3f s\n", what,
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 
 struct CsrView {
     int rows = 0, cols = 0;

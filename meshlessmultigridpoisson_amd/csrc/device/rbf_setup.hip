@@ -8,14 +8,19 @@
 //   shifting_scaling            general_computation_functions.cpp:82-134
 // each of which ends in Eigen's fullPivLu().solve of an (ss+pt) x (ss+pt) saddle system
 // (ss = stencil size, pt = polynomial terms; 70 x 70 for the 3-D degree-3 stencils of the
-// 1e7-point configuration).  One 64-lane workgroup == one wavefront owns one stencil at a
-// time: coordinates are shifted/scaled in registers, the system is assembled column-major in
-// LDS, factorised in place with FULL pivoting (the search for the next pivot is fused into the
-// rank-1 update, ties resolved like a column-major scan: smallest column, then smallest row),
-// every requested right-hand side is solved against the one factorisation.  No inter-wave
-// synchronisation; a wavefront's LDS accesses are in order.  Compute/LDS-bound setup work,
-// not part of the timed hot path.
+// 1e7-point configuration).  One workgroup owns one stencil at a time: coordinates are
+// shifted/scaled in registers, the system is assembled column-major in LDS, factorised in place
+// with FULL pivoting (the search for the next pivot is fused into the rank-1 update, ties
+// resolved like a column-major scan: smallest column, then smallest row), every requested
+// right-hand side is solved against the one factorisation.  The factorisation is a chain of
+// (ss+pt) dependent steps of LDS round trips: with ONE wavefront per stencil the four SIMDs of a
+// CU each crawl along their own chain (LDS capacity allows only four 70 x 70 systems per CU);
+// 256 threads per stencil put four wavefronts on every chain step (NT = 256, barriers between
+// the steps), 64 threads remain for the small 2-D systems.  LDS-latency-bound setup work, not
+// part of the timed hot path.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "rbf_setup.hpp"
 
@@ -35,6 +40,26 @@ __device__ __forceinline__ double wmin(double v)
     return v;
 }
 
+// block-wide max / min of six values at once (bounding box); red: 6 * (NT / 64) doubles of LDS
+template <int NT>
+__device__ __forceinline__ void block_minmax(double &lox, double &hix, double &loy, double &hiy, double &loz, double &hiz, double *red)
+{
+    lox = wmin(lox); hix = wmax(hix); loy = wmin(loy); hiy = wmax(hiy); loz = wmin(loz); hiz = wmax(hiz);
+    if (NT > 64) {
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            red[6 * wave] = lox; red[6 * wave + 1] = hix; red[6 * wave + 2] = loy;
+            red[6 * wave + 3] = hiy; red[6 * wave + 4] = loz; red[6 * wave + 5] = hiz;
+        }
+        __syncthreads();
+        for (int w = 0; w < NT / 64; ++w) {
+            lox = fmin(lox, red[6 * w]); hix = fmax(hix, red[6 * w + 1]); loy = fmin(loy, red[6 * w + 2]);
+            hiy = fmax(hiy, red[6 * w + 3]); loz = fmin(loz, red[6 * w + 4]); hiz = fmax(hiz, red[6 * w + 5]);
+        }
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ double ipow(double x, int e)
 {
     double r = 1.0;
@@ -50,13 +75,14 @@ __device__ __forceinline__ double phs(double d, double m)
     return d > 0.0 ? pow(d, m) : 0.0;
 }
 
-// One wavefront, one stencil at a time.  LDS layout (doubles):
-//   A[n*ld] | rhs[n_ops*n] | sx[ss] sy[ss] sz[ss] (y[n] reuses this space in the solves) |
-//   (ints) cperm[n] ea[pt] eb[pt] ec[pt]
-__global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
+// One workgroup of NT threads, one stencil at a time.  LDS layout (doubles):
+//   A[n*ld] | rhs[n_ops*n] | sx[ss] sy[ss] sz[ss] (y[n] reuses this space in the solves) | red[6 * NT/64] |
+//   (ints) redi[NT/64] cperm[n] ea[pt] eb[pt] ec[pt]
+template <int NT>
+__global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;  // thread of the workgroup
     const int ss = a.ss, pt = a.pt, n = ss + pt, ld = a.ld;
     double *A = reinterpret_cast<double *>(smem);
     double *rhs = A + (size_t)n * ld;
@@ -64,7 +90,9 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
     double *sy = sx + ss;
     double *sz = sy + ss;
     double *yv = sx;  // coordinates are dead once the system and its right-hand sides exist (3 ss >= n)
-    int *cperm = reinterpret_cast<int *>(sz + ss);
+    double *red = sz + ss;
+    int *redi = reinterpret_cast<int *>(red + 6 * (NT / 64));
+    int *cperm = redi + NT / 64;
     int *ea = cperm + n;
     int *eb = ea + pt;
     int *ec = eb + pt;
@@ -87,7 +115,7 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
     for (long long e = blockIdx.x; e < a.n_eval; e += gridDim.x) {
         // ---- shifting_scaling: bounding box of the stencil points, longest side = scale ----
         double lox = 1e300, hix = -1e300, loy = 1e300, hiy = -1e300, loz = 1e300, hiz = -1e300;
-        for (int i = lane; i < ss; i += 64) {
+        for (int i = lane; i < ss; i += NT) {
             const long long id = a.nbr[e * ss + i];
             const double x = a.cloud[3 * id], y = a.cloud[3 * id + 1], z = a.cloud[3 * id + 2];
             sx[i] = x; sy[i] = y; sz[i] = z;
@@ -95,15 +123,11 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
             loy = fmin(loy, y); hiy = fmax(hiy, y);
             loz = fmin(loz, z); hiz = fmax(hiz, z);
         }
-        lox = wmin(lox); hix = wmax(hix); loy = wmin(loy); hiy = wmax(hiy);
+        block_minmax<NT>(lox, hix, loy, hiy, loz, hiz, red);
         double scale = fmax(hix - lox, hiy - loy);
-        if (a.dim >= 3) {
-            loz = wmin(loz); hiz = wmax(hiz);
-            scale = fmax(scale, hiz - loz);
-        } else {
-            loz = 0.0;
-        }
-        for (int i = lane; i < ss; i += 64) {
+        if (a.dim >= 3) scale = fmax(scale, hiz - loz);
+        else loz = 0.0;
+        for (int i = lane; i < ss; i += NT) {
             sx[i] = (sx[i] - lox) / scale;
             sy[i] = (sy[i] - loy) / scale;
             sz[i] = a.dim >= 3 ? (sz[i] - loz) / scale : 0.0;
@@ -115,7 +139,7 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
         // ---- assemble [Phi P; P^T 0] column-major, track the first pivot --------------------
         double best = -1.0;
         int bidx = 0x7fffffff;
-        for (int idx = lane; idx < n * n; idx += 64) {
+        for (int idx = lane; idx < n * n; idx += NT) {
             const int j = idx / n, i = idx - j * n;
             double v = 0.0;
             if (i < ss && j < ss) {
@@ -132,7 +156,7 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
         // ---- right-hand sides (grid.cpp:312-331, :351-370, :389-413, :697-707) -------------
         for (int o = 0; o < a.n_ops; ++o) {
             const int op = a.ops[o];
-            for (int i = lane; i < n; i += 64) {
+            for (int i = lane; i < n; i += NT) {
                 double v = 0.0;
                 if (i < ss) {
                     const double xr = sx[i], yr = sy[i], zr = sz[i];
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
                 rhs[(size_t)o * n + i] = v;
             }
         }
-        for (int i = lane; i < n; i += 64) cperm[i] = i;
+        for (int i = lane; i < n; i += NT) cperm[i] = i;
         __syncthreads();
 
         // ---- full-pivot LU, in place ---------------------------------------------------------
@@ -181,11 +205,22 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
                 const int oi = __shfl_xor(bidx, msk, 64);
                 if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
             }
+            if (NT > 64) {  // ... and of the wavefronts
+                if ((lane & 63) == 0) { red[lane >> 6] = best; redi[lane >> 6] = bidx; }
+                __syncthreads();
+                best = red[0];
+                bidx = redi[0];
+                for (int w = 1; w < NT / 64; ++w) {
+                    const double ob = red[w];
+                    const int oi = redi[w];
+                    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                }
+            }
             if (!(best > 0.0)) { rank = k; break; }
             const int m0 = n - k;                      // the search ran over the m0 x m0 trailing block
             const int pc = k + bidx / m0, pr = k + (bidx - (bidx / m0) * m0);
             if (pr != k) {
-                for (int j = lane; j < n; j += 64) {
+                for (int j = lane; j < n; j += NT) {
                     const double t = A[(size_t)j * ld + k];
                     A[(size_t)j * ld + k] = A[(size_t)j * ld + pr];
                     A[(size_t)j * ld + pr] = t;
@@ -198,7 +233,7 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
             }
             __syncthreads();
             if (pc != k) {
-                for (int i = lane; i < n; i += 64) {
+                for (int i = lane; i < n; i += NT) {
                     const double t = A[(size_t)k * ld + i];
                     A[(size_t)k * ld + i] = A[(size_t)pc * ld + i];
                     A[(size_t)pc * ld + i] = t;
@@ -208,15 +243,15 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
             __syncthreads();
             const double piv = A[(size_t)k * ld + k];
             const int m = n - k - 1;
-            for (int i = lane; i < m; i += 64) A[(size_t)k * ld + k + 1 + i] /= piv;
+            for (int i = lane; i < m; i += NT) A[(size_t)k * ld + k + 1 + i] /= piv;
             __syncthreads();
             // rank-1 update of the trailing m x m block + search of the next pivot
             best = -1.0;
             bidx = 0x7fffffff;
             if (m > 0) {
-                const int sj = 64 / m, si = 64 - sj * m;
+                const int sj = NT / m, si = NT - sj * m;
                 int j = lane / m, i = lane - j * m;
-                for (int idx = lane; idx < m * m; idx += 64) {
+                for (int idx = lane; idx < m * m; idx += NT) {
                     double *col = A + (size_t)(k + 1 + j) * ld;
                     const double v = col[k + 1 + i] - A[(size_t)k * ld + k + 1 + i] * col[k];
                     col[k + 1 + i] = v;
@@ -234,21 +269,21 @@ __global__ __launch_bounds__(64) void rbf_weights_kernel(RbfArgs a)
             double *b = rhs + (size_t)o * n;
             for (int k = 0; k < rank; ++k) {
                 const double bk = b[k];
-                for (int i = k + 1 + lane; i < n; i += 64) b[i] -= A[(size_t)k * ld + i] * bk;
+                for (int i = k + 1 + lane; i < n; i += NT) b[i] -= A[(size_t)k * ld + i] * bk;
                 __syncthreads();
             }
-            for (int i = lane; i < n; i += 64) yv[i] = 0.0;
+            for (int i = lane; i < n; i += NT) yv[i] = 0.0;
             __syncthreads();
             for (int k = rank - 1; k >= 0; --k) {
                 const double yk = b[k] / A[(size_t)k * ld + k];
                 if (lane == 0) yv[k] = yk;
-                for (int i = lane; i < k; i += 64) b[i] -= A[(size_t)k * ld + i] * yk;
+                for (int i = lane; i < k; i += NT) b[i] -= A[(size_t)k * ld + i] * yk;
                 __syncthreads();
             }
             const int op = a.ops[o];
             const double div = op == RBF_OP_LAPLACE ? scale * scale : (op == RBF_OP_INTERP ? 1.0 : scale);
             // weights of the stencil points only (the polynomial multipliers are dropped by every caller)
-            for (int k = lane; k < n; k += 64) {
+            for (int k = lane; k < n; k += NT) {
                 const int c = cperm[k];
                 if (c < ss) a.w[((size_t)o * a.n_eval + e) * ss + c] = yv[k] / div;
             }
@@ -264,16 +299,28 @@ size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out)
     const int n = ss + pt;
     const int ld = n;  // 70 x 70 doubles + the rest stay below 40 KiB: four workgroups per CU
     if (ld_out) *ld_out = ld;
-    size_t d = (size_t)n * ld + (size_t)n_ops * n + 3 * (size_t)ss;
-    return d * 8 + ((size_t)n + 3 * (size_t)pt) * 4 + 16;
+    size_t d = (size_t)n * ld + (size_t)n_ops * n + 3 * (size_t)ss + 6 * 4;
+    return d * 8 + (4 + (size_t)n + 3 * (size_t)pt) * 4 + 16;
+}
+
+int rbf_threads(int ss, int pt)
+{
+    static const int forced = []() {
+        const char *e = std::getenv("MMG_RBF_THREADS");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 64 || forced == 256) return forced;
+    return ss + pt >= 48 ? 256 : 64;
 }
 
 hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rbf_weights_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nt = rbf_threads(a.ss, a.pt);
+    const void *fn = nt == 256 ? reinterpret_cast<const void *>(&rbf_weights_kernel<256>) : reinterpret_cast<const void *>(&rbf_weights_kernel<64>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rbf_weights_kernel, dim3((unsigned)blocks), dim3(64), lds, s, a);
+    if (nt == 256) hipLaunchKernelGGL(rbf_weights_kernel<256>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(rbf_weights_kernel<64>, dim3((unsigned)blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -332,7 +332,7 @@ void Grid::build_deriv_normal_bound()
 int Grid::default_device_setup = -1;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
-                            const vector<int> &ops, vector<int> &nbr, vector<double> &w)
+                            const vector<int> &ops, vector<int> &nbr, vector<double> &w, bool by_column)
 {
     const long long ne = (long long)evals.size();
     if (device_setup_ == 0 || ne == 0) return false;
@@ -342,19 +342,6 @@ bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *eval
     }
     const int ss = stencilSizeFor(polyDeg, dim_);
     if ((int)points_.size() < ss) return false;
-    ensure_knn();
-    nbr.assign((size_t)ne * (size_t)ss, 0);
-    std::atomic<int> short_rows{0};
-    std::unique_ptr<mmgh::SetupTimer> tk(new mmgh::SetupTimer("batched_stencils: kNN (host)"));
-    parallel_for((int)ne, threads(), [&](int e) {
-        const bool isb = evalIsBoundary ? (*evalIsBoundary)[(size_t)e] != 0 : false;
-        const vector<int> nb = kNearestNeighbors(evals[(size_t)e], neumann, isb, ss);
-        if ((int)nb.size() != ss) { short_rows++; return; }
-        std::copy(nb.begin(), nb.end(), nbr.begin() + (size_t)e * (size_t)ss);
-    });
-    tk.reset();
-    if (short_rows.load() > 0) return false;  // fewer candidates than the stencil wants: host path decides
-    mmgh::SetupTimer tw("batched_stencils: weights (device)");
     std::vector<double> cloud(points_.size() * 3), ev((size_t)ne * 3);
     for (size_t i = 0; i < points_.size(); ++i) {
         cloud[3 * i] = std::get<0>(points_[i]);
@@ -366,11 +353,112 @@ bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *eval
         ev[3 * e + 1] = std::get<1>(evals[e]);
         ev[3 * e + 2] = std::get<2>(evals[e]);
     }
+    nbr.assign((size_t)ne * (size_t)ss, 0);
     w.assign(ops.size() * (size_t)ne * (size_t)ss, 0.0);
+    if (ss <= 256) {
+        // neighbour search and dense solves in one call: the lists stay on the MI355X in between
+        mmgh::SetupTimer tw("batched_stencils: kNN + weights (device)");
+        std::vector<unsigned char> cflag, qflag;
+        if (neumann && evalIsBoundary) {  // a Neumann grid's boundary point ignores the other boundary points
+            cflag.resize(points_.size());
+            for (size_t i = 0; i < points_.size(); ++i) cflag[i] = bcFlags_[i] != 0;
+            qflag.assign(evalIsBoundary->begin(), evalIsBoundary->end());
+        }
+        int short_rows = 0;
+        dev_check(mmg_rbf_stencils(dim_, polyDeg, (double)properties_.rbfExp, ss, (int)points_.size(), cloud.data(),
+                                   cflag.empty() ? nullptr : cflag.data(), ne, ev.data(), qflag.empty() ? nullptr : qflag.data(),
+                                   (int)ops.size(), ops.data(), by_column ? 1 : 0, nbr.data(), w.data(), &short_rows),
+                  "mmg_rbf_stencils");
+        return short_rows == 0;  // fewer candidates than the stencil wants: host path decides
+    }
+    ensure_knn();
+    std::atomic<int> short_rows{0};
+    std::unique_ptr<mmgh::SetupTimer> tk(new mmgh::SetupTimer("batched_stencils: kNN (host)"));
+    parallel_for((int)ne, threads(), [&](int e) {
+        const bool isb = evalIsBoundary ? (*evalIsBoundary)[(size_t)e] != 0 : false;
+        const vector<int> nb = kNearestNeighbors(evals[(size_t)e], neumann, isb, ss);
+        if ((int)nb.size() != ss) { short_rows++; return; }
+        std::copy(nb.begin(), nb.end(), nbr.begin() + (size_t)e * (size_t)ss);
+    });
+    tk.reset();
+    if (short_rows.load() > 0) return false;
+    mmgh::SetupTimer tw("batched_stencils: weights (device)");
     dev_check(mmg_rbf_weights(dim_, polyDeg, (double)properties_.rbfExp, ss, (int)points_.size(), cloud.data(), ne, ev.data(),
                               nbr.data(), (int)ops.size(), ops.data(), w.data()),
               "mmg_rbf_weights");
+    if (by_column)
+        parallel_for((int)ne, threads(), [&](int e) {
+            std::vector<std::pair<int, int>> key((size_t)ss);
+            for (int j = 0; j < ss; ++j) key[(size_t)j] = {nbr[(size_t)e * ss + j], j};
+            std::sort(key.begin(), key.end());
+            std::vector<double> t((size_t)ss);
+            for (size_t o = 0; o < ops.size(); ++o) {
+                double *row = w.data() + (o * (size_t)ne + (size_t)e) * (size_t)ss;
+                for (int j = 0; j < ss; ++j) t[(size_t)j] = row[key[(size_t)j].second];
+                std::copy(t.begin(), t.end(), row);
+            }
+            for (int j = 0; j < ss; ++j) nbr[(size_t)e * ss + j] = key[(size_t)j].first;
+        });
     return true;
+}
+
+// Grid::kNearestNeighbors for many points: on the device when it pays (mmg_knn), else on the host threads.
+// flat[id * k .. id * k + len[id]) = the neighbours of point id (rows of points not in ids[] stay empty).
+void Grid::knn_batch(const vector<int> &ids, int k, vector<int> &flat, vector<int> &len)
+{
+    const long long ne = (long long)ids.size();
+    const size_t np = points_.size();
+    flat.assign(np * (size_t)k, -1);
+    len.assign(np, 0);
+    int ndev = 0;
+    const bool dev = k <= 256 && device_setup_ != 0 &&
+                     (device_setup_ > 0 || (ne >= kDeviceSetupMin && mmg_device_count(&ndev) == MMG_OK && ndev >= 1));
+    if (dev) {
+        std::vector<double> cloud(np * 3), qbuf;
+        std::vector<unsigned char> cflag, qflag;
+        if (neumannFlag_) cflag.resize(np);
+        parallel_for((int)np, threads(), [&](int i) {
+            cloud[3 * (size_t)i] = std::get<0>(points_[(size_t)i]);
+            cloud[3 * (size_t)i + 1] = std::get<1>(points_[(size_t)i]);
+            cloud[3 * (size_t)i + 2] = std::get<2>(points_[(size_t)i]);
+            if (neumannFlag_) cflag[(size_t)i] = bcFlags_[(size_t)i] != 0;
+        });
+        bool all = (size_t)ne == np;
+        for (size_t e = 0; all && e < (size_t)ne; ++e) all = ids[e] == (int)e;
+        const double *q = cloud.data();
+        const unsigned char *qf = cflag.empty() ? nullptr : cflag.data();
+        std::vector<int> tmp;
+        if (!all) {
+            qbuf.resize((size_t)ne * 3);
+            if (neumannFlag_) qflag.resize((size_t)ne);
+            parallel_for((int)ne, threads(), [&](int e) {
+                const size_t i = (size_t)ids[(size_t)e];
+                for (int a = 0; a < 3; ++a) qbuf[3 * (size_t)e + a] = cloud[3 * i + a];
+                if (neumannFlag_) qflag[(size_t)e] = cflag[i];
+            });
+            q = qbuf.data();
+            qf = qflag.empty() ? nullptr : qflag.data();
+            tmp.resize((size_t)ne * (size_t)k);
+        }
+        int *rows = all ? flat.data() : tmp.data();
+        dev_check(mmg_knn(dim_, (int)np, cloud.data(), cflag.empty() ? nullptr : cflag.data(), ne, q, qf, k, rows), "mmg_knn");
+        parallel_for((int)ne, threads(), [&](int e) {
+            const int *row = rows + (size_t)e * (size_t)k;
+            int l = k;
+            while (l > 0 && row[l - 1] < 0) --l;
+            const size_t i = (size_t)ids[(size_t)e];
+            len[i] = l;
+            if (!all) std::copy(row, row + k, flat.begin() + (long)(i * (size_t)k));
+        });
+        return;
+    }
+    ensure_knn();
+    parallel_for((int)ne, threads(), [&](int e) {
+        const int i = ids[(size_t)e];
+        const vector<int> nb = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, k);
+        len[(size_t)i] = (int)nb.size();
+        std::copy(nb.begin(), nb.end(), flat.begin() + (long)((size_t)i * (size_t)k));
+    });
 }
 
 // grid.cpp:549-663
@@ -379,14 +467,16 @@ void Grid::build_laplacian()
     mmgh::SetupTimer tt("build_laplacian (total)");
     invalidate_device();
     const int n = laplaceMatSize_;
-    ensure_knn();
-    std::vector<std::vector<double>> W((size_t)n);
-    std::vector<vector<int>> NB((size_t)n);
+    std::vector<std::vector<double>> W;
+    std::vector<vector<int>> NB;
     {
         // batched on the device when it pays (see batched_stencils); rows of ghost points do not exist
         vector<int> ids;
         vector<Point> ev;
         vector<char> isb;
+        ids.reserve((size_t)n);
+        ev.reserve((size_t)n);
+        isb.reserve((size_t)n);
         for (int i = 0; i < n; ++i)
             if (bcFlags_[(size_t)i] != kGhost) {
                 ids.push_back(i);
@@ -396,13 +486,13 @@ void Grid::build_laplacian()
         vector<int> nbr;
         vector<double> w;
         const int ss = stencilSizeFor(properties_.polyDeg, dim_);
-        if (batched_stencils(ev, &isb, neumannFlag_, properties_.polyDeg, {(int)OP_LAPLACE}, nbr, w)) {
+        // Dirichlet problems: every row is its stencil -- with the rows in ascending column order the lists ARE
+        // the CSR arrays (same result as setFromTriplets: columns ascending, no duplicates in a kNN row)
+        if (batched_stencils(ev, &isb, neumannFlag_, properties_.polyDeg, {(int)OP_LAPLACE}, nbr, w, !neumannFlag_)) {
             vector<Point>().swap(ev);
             if (!neumannFlag_) {
-                // Dirichlet problems: every row is its stencil -- assemble the CSR directly
-                // (same result as setFromTriplets: columns ascending, no duplicates in a kNN row)
-                std::vector<int> outer((size_t)n + 1, 0), inner(ids.size() * (size_t)ss);
-                std::vector<double> val(ids.size() * (size_t)ss);
+                mmgh::SetupTimer ta("build_laplacian: CSR");
+                std::vector<int> outer((size_t)n + 1, 0);
                 {
                     size_t k = 0;
                     for (int i = 0; i < n; ++i) {
@@ -414,29 +504,28 @@ void Grid::build_laplacian()
                 std::vector<double> &dg = diags.host_mut();
                 parallel_for((int)ids.size(), threads(), [&](int k) {
                     const int i = ids[(size_t)k];
-                    std::vector<std::pair<int, double>> row((size_t)ss);
-                    for (int j = 0; j < ss; ++j) row[(size_t)j] = {nbr[(size_t)k * ss + j], w[(size_t)k * ss + j]};
-                    std::sort(row.begin(), row.end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
-                    const size_t base = (size_t)outer[(size_t)i];
-                    for (int j = 0; j < ss; ++j) {
-                        inner[base + j] = row[(size_t)j].first;
-                        val[base + j] = row[(size_t)j].second;
-                        if (row[(size_t)j].first == i) dg[(size_t)i] = row[(size_t)j].second;
-                    }
+                    const int *row = nbr.data() + (size_t)k * (size_t)ss;
+                    const int *hit = std::lower_bound(row, row + ss, i);
+                    if (hit != row + ss && *hit == i) dg[(size_t)i] = w[(size_t)k * (size_t)ss + (size_t)(hit - row)];
                 });
                 const int rows = laplaceMat_->rows();
                 delete laplaceMat_;
                 laplaceMat_ = new SparseRowMajor(rows, rows, true);
-                laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(val));
+                laplaceMat_->adopt(std::move(outer), std::move(nbr), std::move(w));
                 vector<Triplet> none;
                 neumann_boundary_coeffs_->setFromTriplets(none.begin(), none.end());
                 return;
             }
+            W.resize((size_t)n);
+            NB.resize((size_t)n);
             for (size_t k = 0; k < ids.size(); ++k) {
                 W[(size_t)ids[k]].assign(w.begin() + (long)(k * ss), w.begin() + (long)((k + 1) * ss));
                 NB[(size_t)ids[k]].assign(nbr.begin() + (long)(k * ss), nbr.begin() + (long)((k + 1) * ss));
             }
         } else {
+            W.resize((size_t)n);
+            NB.resize((size_t)n);
+            ensure_knn();
             parallel_for(n, threads(), [&](int i) {
                 if (bcFlags_[(size_t)i] == kGhost) return;  // ghost points own no row
                 auto w1 = laplaceWeights(i);

@@ -137,12 +137,13 @@ public:
     std::pair<VectorXd, vector<int>> derivy_weights(int pointID);                  // grid.cpp:343-380
     std::pair<VectorXd, vector<int>> derivz_weights(int pointID);                  // 3-D extension
     std::pair<VectorXd, vector<int>> pointInterpWeights(Point point, int polyDeg); // grid.cpp:687-712
-    // The same stencils for MANY evaluation points at once: kNN on the host threads, the
-    // (ss+pt)^2 saddle systems on the device.  ops: 0 laplace, 1 d/dx, 2 d/dy, 3 d/dz, 4 interpolation.
-    // nbr[e*ss + j] / w[(o*n_eval + e)*ss + j].  Returns false (nothing computed) when the batch is
-    // to be done by the host path instead.
+    // The same stencils for MANY evaluation points at once: neighbour search and the (ss+pt)^2 saddle
+    // systems on the device.  ops: 0 laplace, 1 d/dx, 2 d/dy, 3 d/dz, 4 interpolation.
+    // nbr[e*ss + j] / w[(o*n_eval + e)*ss + j], nearest first, or in ascending order of the neighbour
+    // id when by_column is set.  Returns false (nothing computed) when the batch is to be done by the
+    // host path instead.
     bool batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
-                          const vector<int> &ops, vector<int> &nbr, vector<double> &w);
+                          const vector<int> &ops, vector<int> &nbr, vector<double> &w, bool by_column = false);
 
     int getSize();
     int getStencilSize();
@@ -161,6 +162,9 @@ protected:
     enum Op { OP_LAPLACE, OP_DX, OP_DY, OP_DZ, OP_INTERP };
     std::pair<VectorXd, vector<int>> stencil_weights(Point point, bool neumann, bool pointBCFlag, int polyDeg, Op op);
     void ensure_knn();
+    // kNearestNeighbors of the points ids[] of this grid (own rules for Neumann boundary points):
+    // flat[id * k .. id * k + len[id])
+    void knn_batch(const vector<int> &ids, int k, vector<int> &flat, vector<int> &len);
     int threads() const;
     mmgh::CellGrid knn_;
     mmg_level *dev_ = nullptr;

@@ -56,9 +56,8 @@ Multigrid::SparseColMajor *Multigrid::buildInterpMatrix(Grid *base, Grid *target
 {
     const int nt = target->getSize();
     const int deg = fracStep_ ? base->properties_.polyDeg : grids_.back().second->properties_.polyDeg;
-    base->kNearestNeighbors(target->points_[0], false, false, 1);  // builds the search grid once, single-threaded
     {
-        // batched on the device when it pays: kNN on the host threads, dense solves on the MI355X
+        // batched on the device when it pays: neighbour search and dense solves on the MI355X
         vector<int> nbr;
         vector<double> w;
         if (base->batched_stencils(target->points_, nullptr, false, deg, {4 /* interpolation */}, nbr, w)) {
@@ -72,6 +71,7 @@ Multigrid::SparseColMajor *Multigrid::buildInterpMatrix(Grid *base, Grid *target
             return m;
         }
     }
+    base->kNearestNeighbors(target->points_[0], false, false, 1);  // builds the search grid once, single-threaded
     std::vector<std::vector<double>> W((size_t)nt);
     std::vector<vector<int>> NB((size_t)nt);
     int nth = base->setup_threads_;

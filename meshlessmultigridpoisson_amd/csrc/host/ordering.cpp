@@ -13,6 +13,7 @@
 // the kNN stencil, plus the fill of the implicit Neumann elimination.
 // libmmgp derives its schedule from the actual matrix, so a mismatch between
 // this prediction and the matrix can cost performance, never correctness.
+#include <memory>
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -86,6 +87,56 @@ void par_for(int n, int nth, F f)
     for (auto &x : th) x.join();
 }
 
+// few, heavy tasks: one at a time per thread
+template <class F>
+void par_tasks(int n, int nth, F f)
+{
+    if (nth <= 1 || n < 2) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < std::min(nth, n); ++t)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        });
+    for (auto &x : th) x.join();
+}
+
+// idx[lo, hi) sorted by (coordinate along ax, index): keys materialised (no indirection in the comparisons),
+// chunks sorted by the threads, then merged pairwise
+void sort_by_axis(const std::vector<Point> &pts, std::vector<int> &idx, int lo, int hi, int ax, int nth)
+{
+    const int n = hi - lo;
+    std::vector<std::pair<double, int>> key((size_t)n), tmp;
+    const int chunks = (nth > 1 && n >= 100000) ? nth : 1;
+    auto cut = [&](int c) { return (int)((long long)n * c / chunks); };
+    par_tasks(chunks, nth, [&](int c) {
+        for (int k = cut(c); k < cut(c + 1); ++k) key[(size_t)k] = {comp(pts[(size_t)idx[(size_t)(lo + k)]], ax), idx[(size_t)(lo + k)]};
+        std::sort(key.begin() + cut(c), key.begin() + cut(c + 1));
+    });
+    if (chunks > 1) {
+        tmp.resize((size_t)n);
+        std::vector<int> b((size_t)chunks + 1);
+        for (int c = 0; c <= chunks; ++c) b[(size_t)c] = cut(c);
+        while (b.size() > 2) {
+            const int pairs = ((int)b.size() - 1) / 2;
+            par_tasks(pairs, nth, [&](int p2) {
+                const int l = b[(size_t)(2 * p2)], m = b[(size_t)(2 * p2 + 1)], r = b[(size_t)(2 * p2 + 2)];
+                std::merge(key.begin() + l, key.begin() + m, key.begin() + m, key.begin() + r, tmp.begin() + l);
+                std::copy(tmp.begin() + l, tmp.begin() + r, key.begin() + l);
+            });
+            std::vector<int> nb;
+            for (size_t i = 0; i < b.size(); i += 2) nb.push_back(b[i]);
+            if (nb.back() != b.back()) nb.push_back(b.back());
+            b.swap(nb);
+        }
+    }
+    for (int k = 0; k < n; ++k) idx[(size_t)(lo + k)] = key[(size_t)k].second;
+}
+
 }  // namespace
 
 void Grid::mc_order_points(int tile_points)
@@ -94,31 +145,49 @@ void Grid::mc_order_points(int tile_points)
     if (tile_points <= 0) tile_points = mmg_auto_tile_points(nOwned_ >= 0 ? nOwned_ : n, dim_, properties_.stencilSize, lanes_per_row_, 0, 0);
     if (tile_points < 8) tile_points = 8;
     mmgh::SetupTimer tt("mc_order_points (total)");
-    ensure_knn();
     const int nth = threads();
 
     // ---- predicted coupling graph (same construction as rcm_order_points) -------
-    vector<vector<int>> adj((size_t)n);
+    // flat kNN rows; the rows the implicit Neumann elimination fills in are kept apart (ext)
+    const int K = properties_.stencilSize;
+    vector<int> adj_flat, adj_len;
+    vector<vector<int>> ext;
     {
         mmgh::SetupTimer tk("mc_order_points: kNN graph");
-        par_for(n, nth, [&](int i) {
-            if (bcFlags_[(size_t)i] == kGhost) return;
-            adj[(size_t)i] = kNearestNeighbors(points_[(size_t)i], neumannFlag_, bcFlags_[(size_t)i] != 0, properties_.stencilSize);
-        });
+        vector<int> ids;
+        ids.reserve((size_t)n);
+        for (int i = 0; i < n; ++i)
+            if (bcFlags_[(size_t)i] != kGhost) ids.push_back(i);
+        knn_batch(ids, K, adj_flat, adj_len);
     }
+    struct Row {
+        const int *b, *e;
+        const int *begin() const { return b; }
+        const int *end() const { return e; }
+    };
+    auto adj = [&](int i) {
+        if (!ext.empty() && !ext[(size_t)i].empty()) return Row{ext[(size_t)i].data(), ext[(size_t)i].data() + ext[(size_t)i].size()};
+        const int *p = adj_flat.data() + (size_t)i * (size_t)K;
+        return Row{p, p + adj_len[(size_t)i]};
+    };
     if (neumannFlag_ && implicitFlag_) {
+        ext.resize((size_t)n);
         for (int i = 0; i < n; ++i) {
             if (bcFlags_[(size_t)i] != 0) continue;
-            const size_t base = adj[(size_t)i].size();
-            for (size_t j = 0; j < base; ++j) {
-                const int a = adj[(size_t)i][j];
+            const Row base = adj(i);
+            vector<int> row(base.begin(), base.end());
+            const size_t nb = row.size();
+            for (size_t j = 0; j < nb; ++j) {
+                const int a = row[j];
                 if (bcFlags_[(size_t)a] != 2) continue;
-                for (int k : adj[(size_t)a])
-                    if (std::find(adj[(size_t)i].begin(), adj[(size_t)i].end(), k) == adj[(size_t)i].end()) adj[(size_t)i].push_back(k);
+                for (int k : adj(a))
+                    if (std::find(row.begin(), row.end(), k) == row.end()) row.push_back(k);
             }
+            if (row.size() > nb) ext[(size_t)i] = std::move(row);
         }
     }
 
+    std::unique_ptr<mmgh::SetupTimer> st(new mmgh::SetupTimer("mc_order_points: tiles"));
     // ---- 1. spatial tiles ---------------------------------------------------------
     // Default: equal-count slabs along x, each cut into equal-count bars along y,
     // each cut into equal-count boxes along z (a logically Cartesian tile grid).
@@ -160,23 +229,17 @@ void Grid::mc_order_points(int tile_points)
         // either side of a cut differ in x-parity, hence in colour -- what the exact (per-phase)
         // ghost exchange needs (mmg_level_set_exchange_mode)
         if (nOwned_ >= 0 && (m[0] & 1)) m[0]++;
-        auto by_axis = [&](int ax) {
-            return [this, ax](int x, int y) {
-                const double vx = comp(points_[(size_t)x], ax), vy = comp(points_[(size_t)y], ax);
-                return vx < vy || (vx == vy && x < y);
-            };
-        };
         auto cut = [](int lo, int hi, int parts, int k) { return lo + (int)((long long)(hi - lo) * k / parts); };
-        std::sort(idx.begin(), idx.end(), by_axis(0));
+        sort_by_axis(points_, idx, 0, n_t, 0, nth);
         vector<std::pair<int, int>> slabs;
         for (int ix = 0; ix < m[0]; ++ix) slabs.emplace_back(cut(0, n_t, m[0], ix), cut(0, n_t, m[0], ix + 1));
         vector<vector<int>> sb((size_t)m[0]), sc((size_t)m[0]);
-        par_for(m[0], nth, [&](int ix) {
+        par_tasks(m[0], nth, [&](int ix) {
             const int lo = slabs[(size_t)ix].first, hi = slabs[(size_t)ix].second;
-            if (dim_ >= 2) std::sort(idx.begin() + lo, idx.begin() + hi, by_axis(1));
+            if (dim_ >= 2) sort_by_axis(points_, idx, lo, hi, 1, 1);
             for (int iy = 0; iy < m[1]; ++iy) {
                 const int l2 = cut(lo, hi, m[1], iy), h2 = cut(lo, hi, m[1], iy + 1);
-                if (dim_ >= 3) std::sort(idx.begin() + l2, idx.begin() + h2, by_axis(2));
+                if (dim_ >= 3) sort_by_axis(points_, idx, l2, h2, 2, 1);
                 for (int iz = 0; iz < m[2]; ++iz) {
                     const int l3 = cut(l2, h2, m[2], iz), h3 = cut(l2, h2, m[2], iz + 1);
                     if (h3 > l3) {
@@ -202,6 +265,7 @@ void Grid::mc_order_points(int tile_points)
         }
 
     // ---- 2. tile graph + colours (only relaxed rows create dependencies) ------------
+    st.reset(new mmgh::SetupTimer("mc_order_points: tile graph"));
     vector<vector<int>> tnb((size_t)nt);
     {
         vector<vector<int>> fwd((size_t)nt);
@@ -210,7 +274,7 @@ void Grid::mc_order_points(int tile_points)
             for (int k = bounds[(size_t)t]; k < bounds[(size_t)t + 1]; ++k) {
                 const int i = idx[(size_t)k];
                 if (bcFlags_[(size_t)i] != 0) continue;
-                for (int j : adj[(size_t)i]) {
+                for (int j : adj(i)) {
                     if (bcFlags_[(size_t)j] != 0) continue;
                     const int tj = tile_of[(size_t)j];
                     if (tj != t && (v.empty() || v.back() != tj)) v.push_back(tj);
@@ -265,6 +329,7 @@ void Grid::mc_order_points(int tile_points)
     }
 
     // ---- 3. point colours inside each tile --------------------------------------------
+    st.reset(new mmgh::SetupTimer("mc_order_points: point colours"));
     vector<int> pcol((size_t)n, 0);
     par_for(nt, nth, [&](int t) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
@@ -272,7 +337,7 @@ void Grid::mc_order_points(int tile_points)
         for (int k = b; k < e; ++k) {
             const int i = idx[(size_t)k];
             if (bcFlags_[(size_t)i] != 0) continue;
-            for (int j : adj[(size_t)i]) {
+            for (int j : adj(i)) {
                 if (j == i || bcFlags_[(size_t)j] != 0 || tile_of[(size_t)j] != t) continue;
                 ladj[(size_t)(k - b)].push_back(pos_in[(size_t)j]);
                 ladj[(size_t)pos_in[(size_t)j]].push_back(k - b);
@@ -293,6 +358,7 @@ void Grid::mc_order_points(int tile_points)
     });
 
     // ---- storage order --------------------------------------------------------------------
+    st.reset(new mmgh::SetupTimer("mc_order_points: storage order"));
     vector<int> torder((size_t)nt);
     std::iota(torder.begin(), torder.end(), 0);
     std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
@@ -314,6 +380,7 @@ void Grid::mc_order_points(int tile_points)
         tptr.push_back((int)order.size());
     }
     order.insert(order.end(), ghost_idx.begin(), ghost_idx.end());
+    st.reset(new mmgh::SetupTimer("mc_order_points: apply_order"));
     apply_order(order);
     tile_ptr_ = tptr;
     tile_colour_ = tcolour;
