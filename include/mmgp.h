@@ -283,6 +283,10 @@ int mmg_rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_c
                      const unsigned char *cloud_flag, long long n_eval, const double *eval_xyz, const unsigned char *eval_flag,
                      int n_ops, const int *ops, int by_column, int *nbr, double *weights, int *short_rows);
 
+/* Host threads the setup stages (plan packing, ordering, assembly) use: MMG_NUM_THREADS, else the CPUs of the
+ * affinity mask capped by the container's CPU quota. */
+int mmg_host_threads(void);
+
 /* ---- setup: k nearest neighbours ----------------------------------------------------------
  * Grid::kNearestNeighbors (grid.cpp:216-260) for many query points at once: nbr[e][0..k) = the indices of the
  * k smallest (distance, index) pairs of query e over the cloud, ascending (distance = sqrt(dx*dx + dy*dy

@@ -466,6 +466,18 @@ class Multigrid:
             _lib.mmgh_mg_destroy(self.h)
             self.h = None
 
+    @staticmethod
+    def last_setup_times():
+        """Wall seconds of the stages of the last constructor call: one entry per grid (cloud -> ordering ->
+        operator), then Multigrid::buildMatrices."""
+        f = lib().mmgh_mg_setup_times
+        f.restype = C.c_int
+        f.argtypes = [_dp, C.c_int]
+        n = f(None, 0)
+        out = np.zeros(max(n, 1))
+        f(out.ctypes.data_as(_dp), n)
+        return [float(v) for v in out[:n]]
+
     @classmethod
     def _from_handle(cls, h, omega, iters):
         self = cls.__new__(cls)

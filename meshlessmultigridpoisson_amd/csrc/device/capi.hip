@@ -1857,6 +1857,8 @@ struct KnnIndex {
 };
 }  // namespace
 
+int mmg_host_threads(void) { return host_threads(); }
+
 int mmg_knn(int dim, int n_cloud, const double *cloud_xyz, const unsigned char *cloud_flag, long long n_query,
             const double *query_xyz, const unsigned char *query_flag, int k, int *nbr)
 {

@@ -2,6 +2,9 @@
 #include "level_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 
 namespace mmg {
 
@@ -196,19 +199,57 @@ void csc_to_csr(int rows, int cols, const int *colptr, const int *rowidx, const 
                 std::vector<int> *rowptr, std::vector<int> *col, std::vector<double> *rval)
 {
     const int nnz = colptr[cols];
+    // every thread owns a contiguous range of columns: it counts its entries per row, then writes them behind
+    // the entries of the threads before it -- columns ascending inside a row == Eigen's column-major
+    // accumulation order
+    int T = 1;
+    if ((long long)nnz >= 100000) {
+        T = std::max(1, std::min(host_threads(), 32));
+    }
+    auto clo = [&](int t) { return (int)((long long)cols * t / T); };
+    auto rlo = [&](int t) { return (int)((long long)rows * t / T); };
+    auto run = [&](const std::function<void(int)> &f) {
+        if (T == 1) { f(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(f, t);
+        for (auto &x : th) x.join();
+    };
+    std::vector<std::vector<int>> cnt((size_t)T);
+    run([&](int t) {
+        std::vector<int> &c = cnt[(size_t)t];
+        c.assign((size_t)rows, 0);
+        for (int p = colptr[clo(t)]; p < colptr[clo(t + 1)]; ++p) c[(size_t)rowidx[p]]++;
+    });
     rowptr->assign((size_t)rows + 1, 0);
-    for (int p = 0; p < nnz; ++p) (*rowptr)[rowidx[p] + 1]++;
-    for (int i = 0; i < rows; ++i) (*rowptr)[i + 1] += (*rowptr)[i];
-    col->resize(nnz);
-    rval->resize(nnz);
-    std::vector<int> cur(rowptr->begin(), rowptr->end() - 1);
-    // columns ascending inside a row == Eigen's column-major accumulation order
-    for (int j = 0; j < cols; ++j)
-        for (int p = colptr[j]; p < colptr[j + 1]; ++p) {
-            const int q = cur[rowidx[p]]++;
-            (*col)[q] = j;
-            (*rval)[q] = val[p];
+    run([&](int t) {  // row totals
+        for (int i = rlo(t); i < rlo(t + 1); ++i) {
+            int s = 0;
+            for (int u = 0; u < T; ++u) s += cnt[(size_t)u][(size_t)i];
+            (*rowptr)[(size_t)i + 1] = s;
         }
+    });
+    for (int i = 0; i < rows; ++i) (*rowptr)[(size_t)i + 1] += (*rowptr)[(size_t)i];
+    run([&](int t) {  // cnt[u][i] -> where thread u's entries of row i start
+        for (int i = rlo(t); i < rlo(t + 1); ++i) {
+            int at = (*rowptr)[(size_t)i];
+            for (int u = 0; u < T; ++u) {
+                const int c = cnt[(size_t)u][(size_t)i];
+                cnt[(size_t)u][(size_t)i] = at;
+                at += c;
+            }
+        }
+    });
+    col->resize((size_t)nnz);
+    rval->resize((size_t)nnz);
+    run([&](int t) {
+        std::vector<int> &c = cnt[(size_t)t];
+        for (int j = clo(t); j < clo(t + 1); ++j)
+            for (int p = colptr[j]; p < colptr[j + 1]; ++p) {
+                const int q = c[(size_t)rowidx[p]]++;
+                (*col)[(size_t)q] = j;
+                (*rval)[(size_t)q] = val[p];
+            }
+    });
 }
 
 }  // namespace mmg

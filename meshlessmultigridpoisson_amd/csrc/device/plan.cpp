@@ -16,13 +16,49 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <memory>
 #include <thread>
 
+#include <sched.h>
+
 namespace mmg {
+
+int host_threads()
+{
+    static const int cached = []() {
+        if (const char *e = std::getenv("MMG_NUM_THREADS")) {
+            const int v = std::atoi(e);
+            if (v > 0) return v;
+        }
+        int n = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+        double quota = 0.0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+            char q[64] = {0};
+            double period = 0.0;
+            if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / period;
+            std::fclose(f);
+        } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            double qu = 0.0, period = 0.0;
+            if (std::fscanf(g, "%lf", &qu) != 1) qu = 0.0;
+            std::fclose(g);
+            if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(h, "%lf", &period) != 1) period = 0.0;
+                std::fclose(h);
+            }
+            if (qu > 0 && period > 0) quota = qu / period;
+        }
+        if (quota >= 1.0) n = std::min(n, (int)(quota + 0.5));
+        return std::max(1, n);
+    }();
+    return cached;
+}
 
 std::vector<int64_t> uniform_tile_ptr(int64_t n_rows, int rows_per_tile)
 {
@@ -111,16 +147,28 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
     };
 
     // ---- pass 2: per-row entry lists, dependencies ------------------------
-    std::vector<std::vector<Entry>> ent(m);
+    // entries of all rows in one array (row k: ent_flat[ent_beg[k] .. + ent_n[k])), dependencies as (later, earlier)
+    // pairs turned into per-row lists by a counting sort: no allocation per row
+    std::vector<int32_t> ent_beg((size_t)m + 1, 0), ent_n((size_t)m, 0);
+    for (int k = 0; k < m; ++k) {
+        const int32_t gid = s.rows[r0 + k];
+        ent_beg[(size_t)k + 1] = ent_beg[(size_t)k] + (A.rowptr[gid + 1] - A.rowptr[gid]);
+    }
+    std::vector<Entry> ent_flat((size_t)ent_beg[(size_t)m]);
+    struct EntSpan {
+        const Entry *p;
+        size_t n;
+        size_t size() const { return n; }
+        const Entry &operator[](size_t i) const { return p[i]; }
+    };
+    auto ent = [&](int k) { return EntSpan{ent_flat.data() + ent_beg[(size_t)k], (size_t)ent_n[(size_t)k]}; };
+    std::vector<std::pair<int32_t, int32_t>> dep_pairs;
     std::vector<double> diag(m, 0.0);
     std::vector<RowMeta> meta(m);
-    std::vector<std::vector<int32_t>> lower;  // coupled earlier rows of the tile
-    if (s.in_place) lower.resize(m);
     for (int k = 0; k < m; ++k) {
         const int32_t gid = s.rows[r0 + k];
         uint16_t flags = 0;
         bool has_diag = false;
-        ent[k].reserve((size_t)(A.rowptr[gid + 1] - A.rowptr[gid]));
         for (int p = A.rowptr[gid]; p < A.rowptr[gid + 1]; ++p) {
             const int32_t col = A.col[p];
             const double v = A.val[p];
@@ -128,20 +176,20 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             if (s.extract_diag && col == gid) {
                 diag[k] = v;
                 has_diag = true;
-                flags |= (uint16_t)((std::min<size_t>(ent[k].size(), 32766) + 1) << 1);
+                flags |= (uint16_t)((std::min<size_t>((size_t)ent_n[(size_t)k], 32766) + 1) << 1);
                 continue;
             }
             if (v == 0.0) continue;
-            ent[k].push_back({slot(col), v});
+            ent_flat[(size_t)ent_beg[(size_t)k] + (size_t)ent_n[(size_t)k]++] = Entry{slot(col), v};
             if (s.in_place && col != gid) {
                 const int32_t pos = c.rowpos[col];
                 if (pos >= 0) {
                     const int32_t tt = c.tile_of[pos];
                     if (tt == t) {
                         const int kk = (int)(pos - r0);
-                        if (kk < k) lower[k].push_back(kk); else lower[kk].push_back(k);
+                        if (kk < k) dep_pairs.emplace_back(k, kk); else dep_pairs.emplace_back(kk, k);
                     } else {
-                        tb.nbr.push_back(tt);
+                        if (tb.nbr.empty() || tb.nbr.back() != tt) tb.nbr.push_back(tt);
                     }
                 }
             }
@@ -150,9 +198,24 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         if (gid >= lo && gid < hi) self = (uint16_t)(gid - lo);
         else if ((s.extract_diag && has_diag) || s.need_self) self = (uint16_t)slot_of[gid];
         meta[k] = RowMeta{(uint32_t)gid, self, flags};
-        tb.nnz += (long long)ent[k].size();
+        tb.nnz += (long long)ent_n[(size_t)k];
     }
     cleanup();
+
+    // coupled earlier rows of the tile, row by row
+    std::vector<int32_t> low_beg((size_t)m + 1, 0), low_idx(dep_pairs.size());
+    for (const auto &pr : dep_pairs) low_beg[(size_t)pr.first + 1]++;
+    for (int k = 0; k < m; ++k) low_beg[(size_t)k + 1] += low_beg[(size_t)k];
+    {
+        std::vector<int32_t> cur(low_beg.begin(), low_beg.end() - 1);
+        for (const auto &pr : dep_pairs) low_idx[(size_t)cur[(size_t)pr.first]++] = pr.second;
+    }
+    struct IntSpan {
+        const int32_t *b, *e;
+        const int32_t *begin() const { return b; }
+        const int32_t *end() const { return e; }
+    };
+    auto lower = [&](int k) { return IntSpan{low_idx.data() + low_beg[(size_t)k], low_idx.data() + low_beg[(size_t)k + 1]}; };
 
     // ---- levels ------------------------------------------------------------
     std::vector<int32_t> level(m, 0);
@@ -160,7 +223,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
     if (s.in_place) {
         for (int k = 0; k < m; ++k) {
             int lv = 0;
-            for (int32_t j : lower[k]) lv = std::max(lv, level[j] + 1);
+            for (int32_t j : lower(k)) lv = std::max(lv, level[j] + 1);
             level[k] = lv;
             n_levels = std::max(n_levels, lv + 1);
         }
@@ -177,14 +240,14 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         for (int k = 0; k < m; ++k) {
             int r = 0;
             if (s.in_place)
-                for (int32_t j : lower[k]) r = std::max(r, round_of[j] + 1);
+                for (int32_t j : lower(k)) r = std::max(r, round_of[j] + 1);
             else
                 r = fill.empty() ? 0 : (int)fill.size() - 1;
             while (r < (int)fill.size() && fill[r] >= cap) ++r;
             if (r >= (int)fill.size()) fill.resize((size_t)r + 1, 0);
             ++fill[r];
             round_of[k] = r;
-            if ((int)((ent[k].size() + L - 1) / L) > P) { tb.err = "rows-too-long-for-dense"; return; }
+            if ((int)((ent(k).size() + L - 1) / L) > P) { tb.err = "rows-too-long-for-dense"; return; }
         }
         const int n_rounds = (int)fill.size();
         std::vector<std::vector<int32_t>> by_round(n_rounds);
@@ -213,7 +276,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     if (!s.extract_diag) ri.inv_diag = 1.0;
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
                     std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &diag[k], 8);
-                    const auto &e = ent[k];
+                    const auto e = ent(k);
                     for (size_t x = 0; x < e.size(); ++x) {
                         const int q = (int)(x / L), lane = (int)(i * L + x % L);
                         std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
@@ -236,7 +299,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             const int g = (int)std::min<size_t>(G, rows.size() - g0);
             int plen = 0;
             for (int i = 0; i < g; ++i)
-                plen = std::max(plen, (int)((ent[rows[g0 + i]].size() + L - 1) / L));
+                plen = std::max(plen, (int)((ent(rows[g0 + i]).size() + L - 1) / L));
             if (plen > 64 && !s.exact) { tb.err = "row too long for lanes_per_row (more than 64 entries per lane)"; return; }
             const size_t W = (size_t)g * L;
             const size_t plen4 = ((size_t)plen + 3) / 4;
@@ -279,7 +342,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     std::memcpy(B + slots_off + si * 2, &zero_slot, 2);
                 }
             for (int i = 0; i < g; ++i) {
-                const auto &e = ent[rows[g0 + i]];
+                const auto e = ent(rows[g0 + i]);
                 for (size_t x = 0; x < e.size(); ++x) {
                     const size_t q = x / L, sub = x % L;
                     const size_t lane = (size_t)i * L + sub;
@@ -344,12 +407,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     // host threads of the plan packer: PlanSpec::n_threads, else MMG_NUM_THREADS, else all hardware threads
     // (one process per GPU on an 8-GPU node: the launcher gives every rank its share, see bench.py)
     int nt = s.n_threads;
-    if (nt <= 0) {
-        const char *e = std::getenv("MMG_NUM_THREADS");
-        nt = e ? std::atoi(e) : 0;
-    }
-    if (nt <= 0) nt = (int)std::thread::hardware_concurrency();
-    if (nt < 1) nt = 1;
+    if (nt <= 0) nt = host_threads();
     nt = std::min(nt, s.n_tiles);
     std::atomic<int> next{0};
     auto worker = [&]() {
@@ -358,6 +416,9 @@ std::string build_plan(const PlanSpec &s, Plan *out)
             const int t = next.fetch_add(1);
             if (t >= s.n_tiles) break;
             build_tile(c, t, slot_of, tb[t]);
+            auto &nb = tb[t].nbr;  // coupled tiles, each once
+            std::sort(nb.begin(), nb.end());
+            nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
         }
     };
     if (nt == 1) worker();
@@ -406,7 +467,8 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     }
     P.n_rows = s.n_rows;
     P.n_groups = (long long)gh_sz;
-    P.stream.resize(stream_sz + 64);  // tail slack: kernels may prefetch past the end
+    P.stream.resize(stream_sz + 64);  // tail slack: kernels may prefetch past the end (left uninitialised: filled below)
+    std::memset(P.stream.data() + stream_sz, 0, 64);
     P.halo.resize(halo_sz);
     P.ghead.resize(gh_sz);
     {
@@ -438,10 +500,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         // symmetrise: edge (a,b) stored at max(a,b) as "depends on min(a,b)"
         std::vector<std::vector<int32_t>> dep(s.n_tiles);
         for (int t = 0; t < s.n_tiles; ++t) {
-            auto &nb = tb[t].nbr;
-            std::sort(nb.begin(), nb.end());
-            nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
-            for (int32_t u : nb) {
+            for (int32_t u : tb[t].nbr) {
                 if (u < t) dep[t].push_back(u);
                 else if (u > t) dep[u].push_back(t);
             }

@@ -42,6 +42,8 @@
 //     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
 #pragma once
 #include <chrono>
+#include <memory>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -49,6 +51,28 @@
 #include <vector>
 
 namespace mmg {
+
+// std::vector whose resize() leaves new elements uninitialised (multi-GB buffers that are overwritten anyway:
+// the zero fill of a plain vector is a serial pass over memory nobody reads)
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind { using other = DefaultInitAlloc<U>; };
+    DefaultInitAlloc() = default;
+    template <class U>
+    DefaultInitAlloc(const DefaultInitAlloc<U> &) {}
+    template <class U>
+    void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T>
+using RawVec = std::vector<T, DefaultInitAlloc<T>>;
+
+// Host threads the setup stages use: MMG_NUM_THREADS, else the CPUs this process may run on (affinity mask)
+// capped by the container's CPU quota (cgroup cpu.max / cfs_quota) -- std::thread::hardware_concurrency()
+// reports every core of the node even where a fraction of them is this process's share.
+int host_threads();
 
 // wall-clock stamps of the setup stages on stderr when MMG_VERBOSE is set (development aid)
 struct StageTimer {
@@ -154,7 +178,7 @@ struct Plan {
     std::vector<TileDesc> tiles;
     std::vector<int32_t> halo;         // input indices staged after the own range
     std::vector<uint32_t> ghead;       // per group: g | plen << 8
-    std::vector<uint8_t> stream;       // packed groups
+    RawVec<uint8_t> stream;            // packed groups
     std::vector<int32_t> phase_ptr;    // n_phases + 1
     std::vector<int32_t> phase_tiles;  // tiles ordered by phase
     // in-place plans: dep_idx[dep_ptr[t]..dep_ptr[t+1]) = earlier tiles coupled to tile t

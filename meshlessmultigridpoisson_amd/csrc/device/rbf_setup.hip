@@ -20,6 +20,8 @@
 // part of the timed hot path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "rbf_setup.hpp"
@@ -75,27 +77,29 @@ __device__ __forceinline__ double phs(double d, double m)
     return d > 0.0 ? pow(d, m) : 0.0;
 }
 
-// One workgroup of NT threads, one stencil at a time.  LDS layout (doubles):
-//   A[n*ld] | rhs[n_ops*n] | sx[ss] sy[ss] sz[ss] (y[n] reuses this space in the solves) | red[6 * NT/64] |
-//   (ints) redi[NT/64] cperm[n] ea[pt] eb[pt] ec[pt]
+// One workgroup of NT threads, one stencil at a time.  LDS layout:
+//   A[n*ld] doubles (its head doubles as the scratch of the bounding-box reduction, before the system exists)
+//   U: sx[ss] sy[ss] sz[ss] while the system is assembled; afterwards rhs[n_ops*n] y[n] (the right-hand sides
+//      wait in registers until the coordinates are dead)
+//   red[8] doubles, redi[8] ints (pivot search across wavefronts), cperm[n] ints, ea/eb/ec[pt] bytes
+// 70 x 70 (3-D, degree 3, one operator): 40 788 bytes -- FOUR workgroups per CU (160 KiB), not three.
 template <int NT>
-__global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
+__global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four waves per SIMD: at most 128 VGPRs
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;  // thread of the workgroup
     const int ss = a.ss, pt = a.pt, n = ss + pt, ld = a.ld;
     double *A = reinterpret_cast<double *>(smem);
-    double *rhs = A + (size_t)n * ld;
-    double *sx = rhs + (size_t)a.n_ops * n;
-    double *sy = sx + ss;
-    double *sz = sy + ss;
-    double *yv = sx;  // coordinates are dead once the system and its right-hand sides exist (3 ss >= n)
-    double *red = sz + ss;
-    int *redi = reinterpret_cast<int *>(red + 6 * (NT / 64));
-    int *cperm = redi + NT / 64;
-    int *ea = cperm + n;
-    int *eb = ea + pt;
-    int *ec = eb + pt;
+    double *U = A + (size_t)n * ld;
+    double *sx = U, *sy = sx + ss, *sz = sy + ss;
+    double *rhs = U, *yv = U + (size_t)a.n_ops * n;
+    const int usz = 3 * ss > (a.n_ops + 1) * n ? 3 * ss : (a.n_ops + 1) * n;
+    double *red = U + usz;
+    int *redi = reinterpret_cast<int *>(red + 8);
+    int *cperm = redi + 8;
+    unsigned char *ea = reinterpret_cast<unsigned char *>(cperm + n);
+    unsigned char *eb = ea + pt;
+    unsigned char *ec = eb + pt;
 
     // monomial exponents in the reference's enumeration order (grid.cpp:285-297)
     if (lane == 0) {
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
             loy = fmin(loy, y); hiy = fmax(hiy, y);
             loz = fmin(loz, z); hiz = fmax(hiz, z);
         }
-        block_minmax<NT>(lox, hix, loy, hiy, loz, hiz, red);
+        block_minmax<NT>(lox, hix, loy, hiy, loz, hiz, A);
         double scale = fmax(hix - lox, hiy - loy);
         if (a.dim >= 3) scale = fmax(scale, hiz - loz);
         else loz = 0.0;
@@ -154,10 +158,16 @@ __global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
             if (av > best) { best = av; bidx = idx; }
         }
         // ---- right-hand sides (grid.cpp:312-331, :351-370, :389-413, :697-707) -------------
-        for (int o = 0; o < a.n_ops; ++o) {
+        // (entry `lane` of every right-hand side stays in a register until the coordinates may be overwritten)
+        double rreg[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o >= a.n_ops) break;
             const int op = a.ops[o];
-            for (int i = lane; i < n; i += NT) {
+            {
+                const int i = lane;
                 double v = 0.0;
+                if (i < n) {
                 if (i < ss) {
                     const double xr = sx[i], yr = sy[i], zr = sz[i];
                     if (op == RBF_OP_LAPLACE) {
@@ -189,10 +199,15 @@ __global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
                         if (cx >= 2) v += cx * (cx - 1) * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 2);
                     }
                 }
-                rhs[(size_t)o * n + i] = v;
+                }
+                rreg[o] = v;
             }
         }
         for (int i = lane; i < n; i += NT) cperm[i] = i;
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < a.n_ops && lane < n) rhs[(size_t)o * n + lane] = rreg[o];
         __syncthreads();
 
         // ---- full-pivot LU, in place ---------------------------------------------------------
@@ -297,10 +312,11 @@ __global__ __launch_bounds__(NT) void rbf_weights_kernel(RbfArgs a)
 size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out)
 {
     const int n = ss + pt;
-    const int ld = n;  // 70 x 70 doubles + the rest stay below 40 KiB: four workgroups per CU
+    const int ld = n;
     if (ld_out) *ld_out = ld;
-    size_t d = (size_t)n * ld + (size_t)n_ops * n + 3 * (size_t)ss + 6 * 4;
-    return d * 8 + (4 + (size_t)n + 3 * (size_t)pt) * 4 + 16;
+    const size_t usz = std::max<size_t>(3 * (size_t)ss, ((size_t)n_ops + 1) * (size_t)n);
+    const size_t bytes = ((size_t)n * ld + usz + 8) * 8 + (8 + (size_t)n) * 4 + 3 * (size_t)pt;
+    return (bytes + 3) & ~(size_t)3;
 }
 
 int rbf_threads(int ss, int pt)
@@ -309,19 +325,30 @@ int rbf_threads(int ss, int pt)
         const char *e = std::getenv("MMG_RBF_THREADS");
         return e ? std::atoi(e) : 0;
     }();
-    if (forced == 64 || forced == 256) return forced;
-    return ss + pt >= 48 ? 256 : 64;
+    int nt = (forced == 64 || forced == 256) ? forced : (ss + pt >= 48 ? 256 : 64);
+    if (nt < ss + pt) nt = 256;  // thread i carries entry i of the right-hand sides
+    return nt;
+}
+
+template <int NT>
+static hipError_t launch_nt(const RbfArgs &a, int blocks, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rbf_weights_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (std::getenv("MMG_VERBOSE")) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rbf_weights_kernel<NT>, NT, lds) == hipSuccess)
+            std::fprintf(stderr, "[setup]   rbf_weights_kernel<%d>: %zu B of LDS, %d workgroups per CU\n", NT, lds, per_cu);
+    }
+    hipLaunchKernelGGL(rbf_weights_kernel<NT>, dim3((unsigned)blocks), dim3(NT), lds, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s)
 {
-    const int nt = rbf_threads(a.ss, a.pt);
-    const void *fn = nt == 256 ? reinterpret_cast<const void *>(&rbf_weights_kernel<256>) : reinterpret_cast<const void *>(&rbf_weights_kernel<64>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    if (nt == 256) hipLaunchKernelGGL(rbf_weights_kernel<256>, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(rbf_weights_kernel<64>, dim3((unsigned)blocks), dim3(64), lds, s, a);
-    return hipGetLastError();
+    if (a.ss + a.pt > 256) return hipErrorInvalidValue;
+    return rbf_threads(a.ss, a.pt) == 256 ? launch_nt<256>(a, blocks, lds, s) : launch_nt<64>(a, blocks, lds, s);
 }
 
 }  // namespace mmg

@@ -139,8 +139,8 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
         // solves on the MI355X; `which` maps to the operator ids 1 (d/dx), 2 (d/dy), 0 (Laplacian)
         vector<char> isb((size_t)n);
         for (int i = 0; i < n; ++i) isb[(size_t)i] = bcFlags_[(size_t)i] != 0;
-        vector<int> nbr;
-        vector<double> w;
+        mmgh::RawVec<int> nbr;
+        mmgh::RawVec<double> w;
         const int ss = stencilSizeFor(properties_.polyDeg, dim_);
         if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, {which == 0 ? 1 : (which == 1 ? 2 : (which == 3 ? 3 : 0))}, nbr, w)) {
             vector<Triplet> trip;

@@ -32,12 +32,13 @@ void parallel_for(int n, int nthreads, F f)
     }
     std::atomic<int> next{0};
     std::vector<std::thread> th;
+    const int chunk = std::max(16, n / (nthreads * 64));  // light bodies: few trips to the shared counter
     for (int t = 0; t < nthreads; ++t)
         th.emplace_back([&]() {
             for (;;) {
-                const int b = next.fetch_add(16);
+                const int b = next.fetch_add(chunk);
                 if (b >= n) break;
-                const int e = std::min(n, b + 16);
+                const int e = std::min(n, b + chunk);
                 for (int i = b; i < e; ++i) f(i);
             }
         });
@@ -85,12 +86,9 @@ Grid::~Grid()
 
 int Grid::threads() const
 {
-    int t = setup_threads_;
-    if (t <= 0) {  // MMG_NUM_THREADS: share of the host cores of this rank (one process per GPU)
-        const char *e = std::getenv("MMG_NUM_THREADS");
-        t = e ? std::atoi(e) : 0;
-    }
-    if (t <= 0) t = (int)std::thread::hardware_concurrency();
+    // MMG_NUM_THREADS (share of the host cores of this rank, one process per GPU), else the CPUs this process
+    // may use: affinity mask capped by the container's quota
+    const int t = setup_threads_ > 0 ? setup_threads_ : mmg_host_threads();
     return std::max(1, t);
 }
 
@@ -332,7 +330,7 @@ void Grid::build_deriv_normal_bound()
 int Grid::default_device_setup = -1;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
-                            const vector<int> &ops, vector<int> &nbr, vector<double> &w, bool by_column)
+                            const vector<int> &ops, mmgh::RawVec<int> &nbr, mmgh::RawVec<double> &w, bool by_column)
 {
     const long long ne = (long long)evals.size();
     if (device_setup_ == 0 || ne == 0) return false;
@@ -342,19 +340,29 @@ bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *eval
     }
     const int ss = stencilSizeFor(polyDeg, dim_);
     if ((int)points_.size() < ss) return false;
-    std::vector<double> cloud(points_.size() * 3), ev((size_t)ne * 3);
-    for (size_t i = 0; i < points_.size(); ++i) {
-        cloud[3 * i] = std::get<0>(points_[i]);
-        cloud[3 * i + 1] = std::get<1>(points_[i]);
-        cloud[3 * i + 2] = std::get<2>(points_[i]);
+    mmgh::RawVec<double> cloud(points_.size() * 3), ev((size_t)ne * 3);
+    parallel_for((int)points_.size(), threads(), [&](int i) {
+        cloud[3 * (size_t)i] = std::get<0>(points_[(size_t)i]);
+        cloud[3 * (size_t)i + 1] = std::get<1>(points_[(size_t)i]);
+        cloud[3 * (size_t)i + 2] = std::get<2>(points_[(size_t)i]);
+    });
+    parallel_for((int)ne, threads(), [&](int e) {
+        ev[3 * (size_t)e] = std::get<0>(evals[(size_t)e]);
+        ev[3 * (size_t)e + 1] = std::get<1>(evals[(size_t)e]);
+        ev[3 * (size_t)e + 2] = std::get<2>(evals[(size_t)e]);
+    });
+    // result arrays: left uninitialised (gigabytes at 1e7 points), their pages touched by all threads
+    nbr.resize((size_t)ne * (size_t)ss);
+    w.resize(ops.size() * (size_t)ne * (size_t)ss);
+    {
+        const size_t page = 4096, nb = nbr.size() * sizeof(int), wb = w.size() * sizeof(double);
+        char *pn = reinterpret_cast<char *>(nbr.data()), *pw = reinterpret_cast<char *>(w.data());
+        const size_t pages_n = (nb + page - 1) / page, pages_w = (wb + page - 1) / page;
+        parallel_for((int)std::min<size_t>(pages_n + pages_w, 0x7fffffff), threads(), [&](int k) {
+            if ((size_t)k < pages_n) pn[(size_t)k * page] = 0;
+            else pw[((size_t)k - pages_n) * page] = 0;
+        });
     }
-    for (size_t e = 0; e < (size_t)ne; ++e) {
-        ev[3 * e] = std::get<0>(evals[e]);
-        ev[3 * e + 1] = std::get<1>(evals[e]);
-        ev[3 * e + 2] = std::get<2>(evals[e]);
-    }
-    nbr.assign((size_t)ne * (size_t)ss, 0);
-    w.assign(ops.size() * (size_t)ne * (size_t)ss, 0.0);
     if (ss <= 256) {
         // neighbour search and dense solves in one call: the lists stay on the MI355X in between
         mmgh::SetupTimer tw("batched_stencils: kNN + weights (device)");
@@ -472,24 +480,33 @@ void Grid::build_laplacian()
     {
         // batched on the device when it pays (see batched_stencils); rows of ghost points do not exist
         vector<int> ids;
-        vector<Point> ev;
+        vector<Point> ev_own;
         vector<char> isb;
-        ids.reserve((size_t)n);
-        ev.reserve((size_t)n);
-        isb.reserve((size_t)n);
-        for (int i = 0; i < n; ++i)
-            if (bcFlags_[(size_t)i] != kGhost) {
-                ids.push_back(i);
-                ev.push_back(points_[(size_t)i]);
-                isb.push_back(bcFlags_[(size_t)i] != 0);
-            }
-        vector<int> nbr;
-        vector<double> w;
+        bool ghosts = (int)points_.size() != n;
+        for (int i = 0; i < n && !ghosts; ++i) ghosts = bcFlags_[(size_t)i] == kGhost;
+        if (!ghosts) {  // every point is an evaluation point: no copies
+            ids.resize((size_t)n);
+            isb.resize((size_t)n);
+            parallel_for(n, threads(), [&](int i) {
+                ids[(size_t)i] = i;
+                isb[(size_t)i] = bcFlags_[(size_t)i] != 0;
+            });
+        } else {
+            for (int i = 0; i < n; ++i)
+                if (bcFlags_[(size_t)i] != kGhost) {
+                    ids.push_back(i);
+                    ev_own.push_back(points_[(size_t)i]);
+                    isb.push_back(bcFlags_[(size_t)i] != 0);
+                }
+        }
+        const vector<Point> &ev = ghosts ? ev_own : points_;
+        mmgh::RawVec<int> nbr;
+        mmgh::RawVec<double> w;
         const int ss = stencilSizeFor(properties_.polyDeg, dim_);
         // Dirichlet problems: every row is its stencil -- with the rows in ascending column order the lists ARE
         // the CSR arrays (same result as setFromTriplets: columns ascending, no duplicates in a kNN row)
         if (batched_stencils(ev, &isb, neumannFlag_, properties_.polyDeg, {(int)OP_LAPLACE}, nbr, w, !neumannFlag_)) {
-            vector<Point>().swap(ev);
+            vector<Point>().swap(ev_own);
             if (!neumannFlag_) {
                 mmgh::SetupTimer ta("build_laplacian: CSR");
                 std::vector<int> outer((size_t)n + 1, 0);
@@ -596,8 +613,8 @@ void Grid::build_graph_laplacian()
     ensure_knn();
     std::vector<int> outer((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) outer[(size_t)i + 1] = outer[(size_t)i] + (bcFlags_[(size_t)i] == kGhost ? 0 : K);
-    std::vector<int> inner((size_t)outer[(size_t)n]);
-    std::vector<double> val((size_t)outer[(size_t)n]);
+    mmgh::RawVec<int> inner((size_t)outer[(size_t)n], 0);
+    mmgh::RawVec<double> val((size_t)outer[(size_t)n], 0.0);
     const double h2 = 1.0 / std::pow((double)n, 2.0 / dim_);
     parallel_for(n, threads(), [&](int i) {
         if (bcFlags_[(size_t)i] == kGhost) return;
@@ -748,8 +765,9 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<in
     // the local multiplier row lists every local non-Neumann point: the device sums the OWNED ones
     // and all-reduces (mmgp.h "multi-GPU").
     const int a_loc = nl + (neumannFlag_ ? 1 : 0);
-    std::vector<int> outer((size_t)a_loc + 1, 0), inner;
-    std::vector<double> v;
+    std::vector<int> outer((size_t)a_loc + 1, 0);
+    mmgh::RawVec<int> inner;
+    mmgh::RawVec<double> v;
     for (int k = 0; k < no; ++k) {
         const int i = owned[(size_t)k];
         for (int p = rp[i]; p < rp[i + 1]; ++p) { inner.push_back(col[p] == n ? nl : local[(size_t)col[p]]); v.push_back(val[p]); }

@@ -143,7 +143,7 @@ public:
     // id when by_column is set.  Returns false (nothing computed) when the batch is to be done by the
     // host path instead.
     bool batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
-                          const vector<int> &ops, vector<int> &nbr, vector<double> &w, bool by_column = false);
+                          const vector<int> &ops, mmgh::RawVec<int> &nbr, mmgh::RawVec<double> &w, bool by_column = false);
 
     int getSize();
     int getStencilSize();

@@ -4,6 +4,7 @@
 // genGmshGridNeumann, :328-343 run_mg_sim, :431-442 testGmshSingleGrid) on
 // clouds handed in by the caller; the drivers themselves (file naming, txt
 // dumps, parameter sweeps) are out of scope.
+#include <chrono>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -130,6 +131,15 @@ const char *mmgh_last_error() { return g_herr.c_str(); }
 // ---- Multigrid scenarios -------------------------------------------------------------------
 // levels coarse -> fine; npts[l] points each, concatenated in xyz.
 // ordering: 0 rcm_order_points (reference), 1 mc_order_points (MI355X), 2 as given.
+// wall time of the stages of the last mmgh_mg_create_square: [l] = grid l (cloud -> ordering -> operator),
+// [nlevels] = Multigrid::buildMatrices (all restriction / prolongation matrices)
+static std::vector<double> g_mg_setup_times;
+int mmgh_mg_setup_times(double *out, int n)
+{
+    for (int i = 0; i < n && i < (int)g_mg_setup_times.size(); ++i) out[i] = g_mg_setup_times[(size_t)i];
+    return (int)g_mg_setup_times.size();
+}
+
 void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, const int *polydeg, int dim, int neumann,
                             int k1, int k2, int ordering, int tile_points, double omega, int iters, int frac_step,
                             const double *bval_abc, int lanes_per_row)
@@ -139,7 +149,11 @@ void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, con
         mg = frac_step ? new FractionalStepMultigrid() : new Multigrid();
         mg->printResiduals_ = false;
         size_t off = 0;
+        g_mg_setup_times.assign((size_t)nlevels + 1, 0.0);
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
         for (int l = 0; l < nlevels; ++l) {
+            const auto t0 = now();
             GridProperties props = make_props(polydeg[l], dim, omega, iters);
             Grid *g;
             if (neumann) g = gen_neumann(xyz + 3 * off, npts[l], dim, props, k1, k2, ordering, tile_points, l != nlevels - 1);
@@ -150,8 +164,11 @@ void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, con
             g->lanes_per_row_ = lanes_per_row;
             mg->addGrid(g);
             off += (size_t)npts[l];
+            g_mg_setup_times[(size_t)l] = since(t0);
         }
+        const auto t1 = now();
         mg->buildMatrices();
+        g_mg_setup_times[(size_t)nlevels] = since(t1);
     });
     if (rc) { delete mg; return nullptr; }
     return mg;
@@ -570,9 +587,7 @@ void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, cons
             std::vector<int> ownedIdx;
             for (int i = 0; i < n; ++i) if (flags_in[i] != Grid::kGhost) ownedIdx.push_back(i);
             probe.kNearestNeighbors(pts[0], false, false, 1);
-            int nth = 0;
-            if (const char *e = std::getenv("MMG_NUM_THREADS")) nth = std::atoi(e);
-            if (nth <= 0) nth = (int)std::max(1u, std::thread::hardware_concurrency());
+            const int nth = std::max(1, mmg_host_threads());
             std::atomic<size_t> next{0};
             std::vector<std::thread> th;
             for (int t = 0; t < nth; ++t)

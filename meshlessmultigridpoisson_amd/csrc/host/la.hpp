@@ -17,9 +17,29 @@
 #include <cmath>
 #include <cstddef>
 #include <functional>
+#include <thread>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace mmgh {
+
+// std::vector whose resize() leaves new elements uninitialised: multi-GB index / value arrays that are
+// overwritten anyway (the zero fill of a plain vector is a serial pass over memory nobody reads)
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind { using other = DefaultInitAlloc<U>; };
+    DefaultInitAlloc() = default;
+    template <class U>
+    DefaultInitAlloc(const DefaultInitAlloc<U> &) {}
+    template <class U>
+    void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args>
+    void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T>
+using RawVec = std::vector<T, DefaultInitAlloc<T>>;
 
 class Vec {
 public:
@@ -173,8 +193,63 @@ public:
         return y;
     }
 
+    // Column-major matrix from uniform row lists: row i holds the ss distinct columns nbr[i*ss ..] with values
+    // w[i*ss ..].  Same arrays as setFromTriplets (rows ascending inside a column) without the triplets: every
+    // thread owns a contiguous range of rows, counts its entries per column, and writes them behind the
+    // entries of the threads before it.
+    void setFromRowLists(int ss, const int *nbr, const double *w, int nthreads)
+    {
+        const size_t nnz = (size_t)rows_ * (size_t)ss;
+        const int T = std::max(1, std::min(nthreads, rows_ / 4096 + 1));
+        std::vector<std::vector<int>> cnt((size_t)T);
+        auto lo = [&](int t) { return (int)((long long)rows_ * t / T); };
+        auto run = [&](const std::function<void(int)> &f) {
+            if (T == 1) { f(0); return; }
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(f, t);
+            for (auto &x : th) x.join();
+        };
+        run([&](int t) {
+            std::vector<int> &c = cnt[(size_t)t];
+            c.assign((size_t)cols_, 0);
+            for (size_t p = (size_t)lo(t) * ss; p < (size_t)lo(t + 1) * ss; ++p) c[(size_t)nbr[p]]++;
+        });
+        outer_.assign((size_t)cols_ + 1, 0);
+        auto clo = [&](int t) { return (int)((long long)cols_ * t / T); };
+        run([&](int t) {  // column totals
+            for (int j = clo(t); j < clo(t + 1); ++j) {
+                int sum = 0;
+                for (int u = 0; u < T; ++u) sum += cnt[(size_t)u][(size_t)j];
+                outer_[(size_t)j + 1] = sum;
+            }
+        });
+        for (int j = 0; j < cols_; ++j) outer_[(size_t)j + 1] += outer_[(size_t)j];
+        run([&](int t) {  // cnt[u][j] -> start of thread u's entries of column j
+            for (int j = clo(t); j < clo(t + 1); ++j) {
+                int at = outer_[(size_t)j];
+                for (int u = 0; u < T; ++u) {
+                    const int c = cnt[(size_t)u][(size_t)j];
+                    cnt[(size_t)u][(size_t)j] = at;
+                    at += c;
+                }
+            }
+        });
+        inner_.resize(nnz);
+        val_.resize(nnz);
+        run([&](int t) {
+            std::vector<int> &c = cnt[(size_t)t];
+            for (int i = lo(t); i < lo(t + 1); ++i)
+                for (int j = 0; j < ss; ++j) {
+                    const size_t p = (size_t)i * ss + (size_t)j;
+                    const int q = c[(size_t)nbr[p]]++;
+                    inner_[(size_t)q] = i;
+                    val_[(size_t)q] = w[p];
+                }
+        });
+    }
+
     // direct assembly from finished arrays (synthetic operators)
-    void adopt(std::vector<int> &&outer, std::vector<int> &&inner, std::vector<double> &&val)
+    void adopt(std::vector<int> &&outer, RawVec<int> &&inner, RawVec<double> &&val)
     {
         outer_ = std::move(outer);
         inner_ = std::move(inner);
@@ -184,8 +259,9 @@ public:
 private:
     int rows_, cols_;
     bool rm_;
-    std::vector<int> outer_, inner_;
-    std::vector<double> val_;
+    std::vector<int> outer_;
+    RawVec<int> inner_;
+    RawVec<double> val_;
 };
 
 // Dense column-major matrix for the (K+polyTerms)^2 stencil systems.

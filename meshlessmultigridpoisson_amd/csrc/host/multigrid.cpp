@@ -58,29 +58,21 @@ Multigrid::SparseColMajor *Multigrid::buildInterpMatrix(Grid *base, Grid *target
     const int deg = fracStep_ ? base->properties_.polyDeg : grids_.back().second->properties_.polyDeg;
     {
         // batched on the device when it pays: neighbour search and dense solves on the MI355X
-        vector<int> nbr;
-        vector<double> w;
+        mmgh::RawVec<int> nbr;
+        mmgh::RawVec<double> w;
         if (base->batched_stencils(target->points_, nullptr, false, deg, {4 /* interpolation */}, nbr, w)) {
             const int ss = Grid::stencilSizeFor(deg, base->dim_);
-            vector<Triplet> trip;
-            trip.reserve((size_t)nt * (size_t)ss);
-            for (int i = 0; i < nt; ++i)
-                for (int j = 0; j < ss; ++j) trip.emplace_back(i, nbr[(size_t)i * ss + j], w[(size_t)i * ss + j]);
+            mmgh::SetupTimer tc("buildInterpMatrix: column-major assembly");
+            const int nth = std::min(32, base->setup_threads_ > 0 ? base->setup_threads_ : mmg_host_threads());
             SparseColMajor *m = new SparseColMajor(nt, base->getSize(), false);
-            m->setFromTriplets(trip.begin(), trip.end());
+            m->setFromRowLists(ss, nbr.data(), w.data(), std::max(1, nth));
             return m;
         }
     }
     base->kNearestNeighbors(target->points_[0], false, false, 1);  // builds the search grid once, single-threaded
     std::vector<std::vector<double>> W((size_t)nt);
     std::vector<vector<int>> NB((size_t)nt);
-    int nth = base->setup_threads_;
-    if (nth <= 0) {
-        const char *e = std::getenv("MMG_NUM_THREADS");
-        nth = e ? std::atoi(e) : 0;
-    }
-    if (nth <= 0) nth = (int)std::thread::hardware_concurrency();
-    nth = std::max(1, std::min(nth, nt / 64 + 1));
+    int nth = std::max(1, std::min(base->setup_threads_ > 0 ? base->setup_threads_ : mmg_host_threads(), nt / 64 + 1));
     std::atomic<int> next{0};
     auto work = [&]() {
         for (;;) {

@@ -362,23 +362,25 @@ void Grid::mc_order_points(int tile_points)
     vector<int> torder((size_t)nt);
     std::iota(torder.begin(), torder.end(), 0);
     std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
-    vector<int> order;
-    order.reserve((size_t)n);
     vector<int> tptr(1, 0);
     vector<int> tcolour;
-    for (int t : torder) tcolour.push_back(tcol[(size_t)t]);
     for (int t : torder) {
+        tcolour.push_back(tcol[(size_t)t]);
+        tptr.push_back(tptr.back() + bounds[(size_t)t + 1] - bounds[(size_t)t]);
+    }
+    vector<int> order((size_t)tptr.back());
+    par_for(nt, nth, [&](int pos) {
+        const int t = torder[(size_t)pos];
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1];
-        vector<int> loc(idx.begin() + b, idx.begin() + e);
-        std::stable_sort(loc.begin(), loc.end(), [&](int x, int y) {
+        int *loc = order.data() + tptr[(size_t)pos];
+        std::copy(idx.begin() + b, idx.begin() + e, loc);
+        std::stable_sort(loc, loc + (e - b), [&](int x, int y) {
             const bool bx = bcFlags_[(size_t)x] != 0, by = bcFlags_[(size_t)y] != 0;
             if (bx != by) return by;  // interior first
             if (bx) return false;
             return pcol[(size_t)x] < pcol[(size_t)y];
         });
-        order.insert(order.end(), loc.begin(), loc.end());
-        tptr.push_back((int)order.size());
-    }
+    });
     order.insert(order.end(), ghost_idx.begin(), ghost_idx.end());
     st.reset(new mmgh::SetupTimer("mc_order_points: apply_order"));
     apply_order(order);
