@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import ctypes
 import os
 import sys
 import time
@@ -93,15 +94,15 @@ def cpu_baseline(grid, stencil, budget_s, lv=None):
     except Exception:
         fast = False
     la = grid.level_arrays()
-    lv = oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"], la["neumann"],
-                  la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"], fast=fast)
+    olv = oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"], la["neumann"],
+                   la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"], fast=fast)
     interior = int((la["bcflags"] == 0).sum())
     t0 = time.perf_counter()
-    lv.sor_sweeps(1)
+    olv.sor_sweeps(1)
     t1 = time.perf_counter() - t0
     n = max(1, min(20, int(budget_s / max(t1, 1e-6)) - 1))
     t0 = time.perf_counter()
-    lv.sor_sweeps(n)
+    olv.sor_sweeps(n)
     dt = time.perf_counter() - t0
     all_cores = None
     try:  # optional all-cores figure: tiles of one colour concurrently (bitwise the sequential sweep) -- baseline only
@@ -109,7 +110,7 @@ def cpu_baseline(grid, stencil, budget_s, lv=None):
         if lv is not None and tp is not None and not la["neumann"]:
             ph = lv.point_phases()
             tile_phase = np.array([max(0, int(ph[tp[t]:tp[t + 1]].max(initial=0))) for t in range(len(tp) - 1)], dtype=np.int32)
-            nthreads = min(os.cpu_count() or 1, 64)
+            nthreads = usable_cpus()
             lv_par = oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"], la["neumann"],
                               la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"], la["bvals"], fast=fast)
             lv_par.sor_sweeps_tiled(1, tp, tile_phase, nthreads)
@@ -127,6 +128,15 @@ def cpu_baseline(grid, stencil, budget_s, lv=None):
             "host": host_description()}
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the container's CPU quota (the GPU box
+    shows every core of the node for a share of 16)."""
+    from meshlessmultigridpoisson_amd import _capi
+    f = _capi.lib().mmg_host_threads
+    f.restype = ctypes.c_int
+    return max(1, int(f()))
+
+
 def host_description():
     """nproc, CPU model, compiler: what BASELINE.md section 2 asks to be stated next to the CPU figure."""
     import subprocess
@@ -142,7 +152,7 @@ def host_description():
         cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
     except Exception:  # noqa: BLE001
         cc = "gcc (version unknown)"
-    return {"nproc": os.cpu_count(), "cpu_model": model, "compiler": cc}
+    return {"nproc": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": model, "compiler": cc}
 
 
 def algorithmic_bytes_per_vcycle(levels, k_interp, iters):
