@@ -253,10 +253,11 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if world > 1 and "MMG_NUM_THREADS" not in os.environ:
-        # one process per GPU: every rank takes its share of the host cores for the (untimed) setup
-        os.environ["MMG_NUM_THREADS"] = str(max(4, (os.cpu_count() or 8) // world))
     from meshlessmultigridpoisson_amd import _capi, _host
+    if world > 1 and "MMG_NUM_THREADS" not in os.environ:
+        # one process per GPU: every rank takes its share of the CPUs the job may use (affinity mask capped by the
+        # container's quota, not os.cpu_count(): the node shows all its cores) for the (untimed) setup
+        os.environ["MMG_NUM_THREADS"] = str(max(2, usable_cpus() // world))
     if _capi.device_count() < 1:
         raise SystemExit("bench.py: no HIP device (libmmgp has no CPU fallback)")
     _capi.check(_capi.lib().mmg_set_device(local_rank))

@@ -29,11 +29,11 @@ namespace mmg {
 
 int host_threads()
 {
+    if (const char *e = std::getenv("MMG_NUM_THREADS")) {  // read every time: a launcher may set it after the first call
+        const int v = std::atoi(e);
+        if (v > 0) return v;
+    }
     static const int cached = []() {
-        if (const char *e = std::getenv("MMG_NUM_THREADS")) {
-            const int v = std::atoi(e);
-            if (v > 0) return v;
-        }
         int n = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
         CPU_ZERO(&set);

@@ -158,13 +158,14 @@ public:
     static int polyTerms(int polyDeg, int dim);
     static int stencilSizeFor(int polyDeg, int dim);
 
+    // kNearestNeighbors of the points ids[] of this grid (own rules for Neumann boundary points):
+    // flat[id * k .. id * k + len[id]); on the device when it pays (mmg_knn), else on the host threads
+    void knn_batch(const vector<int> &ids, int k, vector<int> &flat, vector<int> &len);
+
 protected:
     enum Op { OP_LAPLACE, OP_DX, OP_DY, OP_DZ, OP_INTERP };
     std::pair<VectorXd, vector<int>> stencil_weights(Point point, bool neumann, bool pointBCFlag, int polyDeg, Op op);
     void ensure_knn();
-    // kNearestNeighbors of the points ids[] of this grid (own rules for Neumann boundary points):
-    // flat[id * k .. id * k + len[id])
-    void knn_batch(const vector<int> &ids, int k, vector<int> &flat, vector<int> &len);
     int threads() const;
     mmgh::CellGrid knn_;
     mmg_level *dev_ = nullptr;

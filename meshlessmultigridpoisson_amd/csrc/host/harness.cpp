@@ -583,23 +583,12 @@ void *mmgh_grid_create_local(int n, const double *xyz, const int *flags_in, cons
         {
             Grid probe(pts, std::vector<Boundary>(), props, mmgh::Vec((size_t)n));
             probe.dim_ = dim;
-            std::vector<std::vector<int>> nb((size_t)n);
             std::vector<int> ownedIdx;
             for (int i = 0; i < n; ++i) if (flags_in[i] != Grid::kGhost) ownedIdx.push_back(i);
-            probe.kNearestNeighbors(pts[0], false, false, 1);
-            const int nth = std::max(1, mmg_host_threads());
-            std::atomic<size_t> next{0};
-            std::vector<std::thread> th;
-            for (int t = 0; t < nth; ++t)
-                th.emplace_back([&]() {
-                    for (;;) {
-                        const size_t b = next.fetch_add(256);
-                        if (b >= ownedIdx.size()) break;
-                        for (size_t k = b; k < std::min(ownedIdx.size(), b + 256); ++k)
-                            for (int j : probe.kNearestNeighbors(pts[(size_t)ownedIdx[k]], false, false, stencil)) used[(size_t)j] = 1;
-                    }
-                });
-            for (auto &x : th) x.join();
+            std::vector<int> flat, len;
+            probe.knn_batch(ownedIdx, stencil, flat, len);  // on the device when it pays (mmg_knn)
+            for (int i : ownedIdx)
+                for (int j = 0; j < len[(size_t)i]; ++j) used[(size_t)flat[(size_t)i * (size_t)stencil + (size_t)j]] = 1;
         }
         std::vector<int> keepOwned, ghosts;
         for (int i = 0; i < n; ++i) {
