@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
     ap.add_argument("--graph", type=int, default=1, help="0: issue every launch of the cycle body directly (A/B of the HIP graph)")
     ap.add_argument("--waves", type=int, default=0, help="waves_per_tile option: 0 automatic, 1 packed stream everywhere (A/B)")
+    ap.add_argument("--per-level", type=str, default="", help="write a per-level table (sweep, residual: us, %% of 8 TB/s) to this markdown file")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
     _capi.set_option("persistent_sweep", a.persistent)
@@ -52,6 +53,31 @@ def main():
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
            "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
            "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
+    if a.per_level:
+        import numpy as np
+        lines = [f"## {out['workload']}", "",
+                 f"device {out['device_ms_per_vcycle']:.3f} ms per V-cycle (V({a.iters},{a.iters}), {a.cycles} cycles back to back)", "",
+                 "| level | points | relaxed rows | K | layout (tile points x lanes per row x wavefronts per tile) | tiles | phases | "
+                 "us per sweep | % of 8 TB/s (sweep) | us per residual | % of 8 TB/s (residual) | share of the cycle: 2 x iters sweeps + residual |",
+                 "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+        for l in range(mg.nlevels):
+            g = mg.grid(l)
+            sz = g.sizes()
+            lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
+            info = lv.info()
+            K = _host.stencil_size(polys[l], a.dim)
+            rows = info["sor_rows"]
+            ms_s = lv.time_sweeps(a.iters, 7)
+            us_sweep = float(np.median(ms_s[1:])) / a.iters * 1e3
+            ms_r = lv.time_residual(7)
+            us_res = float(np.median(ms_r[1:])) * 1e3
+            alg = rows * (12 * K + 28)
+            share = (2 * a.iters * us_sweep + us_res) / (out["device_ms_per_vcycle"] * 1e3)
+            lines.append(f"| {l} | {sz['n']} | {rows} | {K} | {sz['n'] // max(1, info['n_tiles'])} x {info['lanes_per_row']} x {info['waves_per_tile']} | "
+                         f"{info['n_tiles']} | {info['n_phases']} | {us_sweep:.1f} | {alg / (us_sweep * 1e-6) / 8e12 * 100:.1f} | "
+                         f"{us_res:.1f} | {rows * (12 * K + 24) / (us_res * 1e-6) / 8e12 * 100:.1f} | {share * 100:.1f} % |")
+        with open(a.per_level, "a") as f:
+            f.write("\n".join(lines) + "\n\n")
     print(json.dumps(out))
 
 
