@@ -79,3 +79,20 @@ def test_auto_tile_points_is_device_free_arithmetic():
     assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 384
     assert _capi.auto_tile_points(190 ** 3, 3, 50, 0, 256, 163840) == 384
     assert _capi.auto_tile_points(10000, 2, 37, 4, 256, 163840) == 256
+
+
+def test_host_threads_follow_the_override_and_the_cpu_share(monkeypatch):
+    """mmg_host_threads: MMG_NUM_THREADS when set (read on every call: bench.py sets it per rank after the library
+    is loaded), else at most the CPUs of the affinity mask (capped by the container's quota, which cannot exceed it)."""
+    import ctypes
+    import os
+    from meshlessmultigridpoisson_amd import _capi
+    f = _capi.lib().mmg_host_threads
+    f.restype = ctypes.c_int
+    monkeypatch.delenv("MMG_NUM_THREADS", raising=False)
+    auto = f()
+    assert 1 <= auto <= len(os.sched_getaffinity(0))
+    monkeypatch.setenv("MMG_NUM_THREADS", "3")
+    assert f() == 3
+    monkeypatch.delenv("MMG_NUM_THREADS")
+    assert f() == auto

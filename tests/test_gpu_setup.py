@@ -1,6 +1,6 @@
-"""GPU tests of the batched setup kernel: mmg_rbf_weights replaces the per-point
-fullPivLu().solve of Grid::laplaceWeights / derivx_weights / derivy_weights / pointInterpWeights
-(grid.cpp:263-424, :687-712).
+"""GPU tests of the setup kernels: mmg_knn replaces Grid::kNearestNeighbors (grid.cpp:216-260,
+identical lists bit for bit), mmg_rbf_weights / mmg_rbf_stencils the per-point fullPivLu().solve of
+Grid::laplaceWeights / derivx_weights / derivy_weights / pointInterpWeights (grid.cpp:263-424, :687-712).
 
 Parity status: the reference ships no fixture for its setup; the checker here is the build's own
 host restatement of those functions (csrc/host/grid.cpp, itself checked against the numpy
@@ -122,10 +122,12 @@ def test_device_setup_fracstep_operators_match_host_setup(host):
     assert np.abs(gh.source() - gd.source()).max() <= 1e-6 * np.abs(gh.source()).max()
 
 
-def test_device_setup_multigrid_converges_like_host_setup(host):
-    """Interpolation matrices + level operators from the device batch: the V-cycle history follows the
-    host-setup hierarchy (same algorithm, operators equal to ~1e-7) and reaches the manufactured solution."""
-    clouds = [host.square_cloud(n, seed=12345 + i) for i, n in enumerate([13, 25, 49])]
+@pytest.mark.parametrize("sides", [[13, 25, 49], [25, 49, 97]])   # 97^2 rows: the threaded column-major assembly
+def test_device_setup_multigrid_converges_like_host_setup(host, sides):
+    """Interpolation matrices + level operators from the device batch (neighbour search, solves, column-major
+    assembly by counting transposition): identical sparsity to the host-setup hierarchy (host search, triplets),
+    values equal to ~1e-7; the V-cycle history follows it and reaches the manufactured solution."""
+    clouds = [host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
     host.set_option("device_setup", 0)
     mh = host.Multigrid(clouds, [3, 3, 4], tile_points=128)
     host.set_option("device_setup", 1)

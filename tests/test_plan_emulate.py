@@ -176,3 +176,32 @@ def test_twelve_bit_slot_stream_and_sixteen_bit_option():
     o.sor_sweeps(2)
     e12n.sweeps(2)
     assert H.rel_err(e12n.x, o.x) < 1e-12
+
+
+def test_threaded_csc_to_csr_keeps_eigens_accumulation_order():
+    """libmmgp's csc_to_csr (mmg_transfer_create for the reference's column-major transfers) runs on all host
+    threads from 1e5 non-zeros on: every thread owns a range of columns and writes behind the threads before it.
+    The product through the packed gather plan must equal scipy's, and -- the rows being summed in ascending
+    column order, Eigen's accumulation order -- be bitwise the sequential row sums."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    rows, cols, per_col = 6000, 5000, 30     # rows stay below 64 entries: one lane sums a whole row
+    rowidx = np.concatenate([np.sort(rng.choice(rows, per_col, replace=False)) for _ in range(cols)]).astype(np.int32)
+    colptr = (np.arange(cols + 1) * per_col).astype(np.int32)
+    val = rng.standard_normal(len(rowidx))
+    x = rng.standard_normal(cols)
+    assert len(rowidx) >= 100000
+    y = H.emu_transfer_apply((rows, cols), colptr, rowidx, val, x, L=1)   # one lane per row: plain sequential sums
+    M = sp.csc_matrix((val, rowidx, colptr), shape=(rows, cols)).tocsr()
+    M.sort_indices()
+    assert np.diff(M.indptr).max() < 64
+    want = M @ x
+    from fractions import Fraction
+    seq = np.zeros(rows)
+    for i in range(rows):           # s = fma(a, x, s) entry by entry, like the kernels and their emulator
+        s = 0.0
+        for p in range(M.indptr[i], M.indptr[i + 1]):
+            s = float(Fraction(float(M.data[p])) * Fraction(float(x[M.indices[p]])) + Fraction(s))
+        seq[i] = s
+    assert np.array_equal(y, seq)
+    assert np.allclose(y, want, rtol=1e-12, atol=1e-12)
