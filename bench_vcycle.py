@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
     ap.add_argument("--graph", type=int, default=1, help="0: issue every launch of the cycle body directly (A/B of the HIP graph)")
     ap.add_argument("--waves", type=int, default=0, help="waves_per_tile option: 0 automatic, 1 packed stream everywhere (A/B)")
+    ap.add_argument("--point-colouring", type=int, default=1, help="0: greedy point colours in tile order (A/B)")
     ap.add_argument("--per-level", type=str, default="", help="write a per-level table (sweep, residual: us, %% of 8 TB/s) to this markdown file")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
@@ -35,6 +36,7 @@ def main():
     _capi.set_option("lds_resident", a.lds_resident)
     _capi.set_option("vcycle_graph", a.graph)
     _capi.set_option("waves_per_tile", a.waves)
+    _host.set_option("point_colouring", a.point_colouring)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
     if a.dim == 3:

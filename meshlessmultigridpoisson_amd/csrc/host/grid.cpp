@@ -74,6 +74,7 @@ Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties pro
     neumann_boundary_coeffs_ = new SparseRowMajor(A_size, A_size, true);
     diags = VectorXd((size_t)A_size);
     device_setup_ = default_device_setup;
+    point_colouring_ = default_point_colouring;
 }
 
 Grid::~Grid()
@@ -328,6 +329,7 @@ void Grid::build_deriv_normal_bound()
 }
 
 int Grid::default_device_setup = -1;
+int Grid::default_point_colouring = 1;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
                             const vector<int> &ops, mmgh::RawVec<int> &nbr, mmgh::RawVec<double> &w, bool by_column)

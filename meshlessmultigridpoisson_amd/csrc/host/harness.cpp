@@ -674,6 +674,7 @@ int mmgh_write_msh(const char *fname, const double *xyz, int n) { return writePo
 int mmgh_set_option(const char *name, int value)
 {
     if (name && std::string(name) == "device_setup") { Grid::default_device_setup = value; return 0; }
+    if (name && std::string(name) == "point_colouring") { Grid::default_point_colouring = value; return 0; }
     g_herr = "mmgh_set_option: unknown option";
     return 1;
 }

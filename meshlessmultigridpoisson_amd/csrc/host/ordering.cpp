@@ -330,7 +330,7 @@ void Grid::mc_order_points(int tile_points)
 
     // ---- 3. point colours inside each tile --------------------------------------------
     st.reset(new mmgh::SetupTimer("mc_order_points: point colours"));
-    vector<int> pcol((size_t)n, 0);
+    vector<int> pcol((size_t)n, 0), tile_ncol((size_t)nt, 0);
     par_for(nt, nth, [&](int t) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
         vector<vector<int>> ladj((size_t)m);
@@ -343,19 +343,90 @@ void Grid::mc_order_points(int tile_points)
                 ladj[(size_t)pos_in[(size_t)j]].push_back(k - b);
             }
         }
-        vector<int> col((size_t)m, -1), mark;
-        for (int k = 0; k < m; ++k) {
-            const int i = idx[(size_t)(b + k)];
-            if (bcFlags_[(size_t)i] != 0) continue;
-            mark.assign(ladj[(size_t)k].size() + 2, 0);
-            for (int u : ladj[(size_t)k])
-                if (col[(size_t)u] >= 0 && col[(size_t)u] < (int)mark.size()) mark[(size_t)col[(size_t)u]] = 1;
-            int c = 0;
-            while (mark[(size_t)c]) ++c;
-            col[(size_t)k] = c;
-            pcol[(size_t)i] = c;
+        // Fewer colours = shorter dependency chains inside the tile (a colour is at least one barrier-separated
+        // round of the tile's wavefronts; the levels below ~2e6 points are bound by exactly that chain).  Greedy
+        // colouring in smallest-last order (Matula-Beck: repeatedly remove a vertex of least remaining degree,
+        // colour in reverse order of removal), then a few rounds of iterated greedy (Culberson: re-run greedy with
+        // the colour classes taken as blocks in reverse order -- never more colours, often fewer).
+        vector<int> col((size_t)m, -1), mark, order;
+        vector<char> relaxed((size_t)m, 0);
+        for (int k = 0; k < m; ++k) relaxed[(size_t)k] = bcFlags_[(size_t)idx[(size_t)(b + k)]] == 0;
+        auto greedy = [&](const vector<int> &ord) {
+            std::fill(col.begin(), col.end(), -1);
+            int used = 0;
+            for (int k : ord) {
+                mark.assign(ladj[(size_t)k].size() + 2, 0);
+                for (int u : ladj[(size_t)k])
+                    if (col[(size_t)u] >= 0 && col[(size_t)u] < (int)mark.size()) mark[(size_t)col[(size_t)u]] = 1;
+                int c = 0;
+                while (mark[(size_t)c]) ++c;
+                col[(size_t)k] = c;
+                used = std::max(used, c + 1);
+            }
+            return used;
+        };
+        if (point_colouring_ == 0 || n_t > 3000000) {  // plain greedy in tile order (round 1; bandwidth-bound levels: the chain is hidden)
+            for (int k = 0; k < m; ++k)
+                if (relaxed[(size_t)k]) order.push_back(k);
+            greedy(order);
+        } else {
+            // smallest-last order by bucket queue
+            vector<int> deg((size_t)m, 0), removed((size_t)m, 0);
+            int maxdeg = 0;
+            for (int k = 0; k < m; ++k)
+                if (relaxed[(size_t)k]) {
+                    auto &v = ladj[(size_t)k];
+                    std::sort(v.begin(), v.end());
+                    v.erase(std::unique(v.begin(), v.end()), v.end());
+                    deg[(size_t)k] = (int)v.size();
+                    maxdeg = std::max(maxdeg, deg[(size_t)k]);
+                }
+            vector<vector<int>> bucket((size_t)maxdeg + 1);
+            int left = 0;
+            for (int k = 0; k < m; ++k)
+                if (relaxed[(size_t)k]) { bucket[(size_t)deg[(size_t)k]].push_back(k); ++left; }
+            vector<int> sl;
+            sl.reserve((size_t)left);
+            int d = 0;
+            while (left > 0) {
+                while (d <= maxdeg && bucket[(size_t)d].empty()) ++d;
+                const int k = bucket[(size_t)d].back();
+                bucket[(size_t)d].pop_back();
+                if (removed[(size_t)k] || deg[(size_t)k] != d) continue;  // stale entry
+                removed[(size_t)k] = 1;
+                sl.push_back(k);
+                --left;
+                for (int u : ladj[(size_t)k])
+                    if (!removed[(size_t)u]) {
+                        --deg[(size_t)u];
+                        bucket[(size_t)deg[(size_t)u]].push_back(u);
+                        if (deg[(size_t)u] < d) d = deg[(size_t)u];
+                    }
+            }
+            order.assign(sl.rbegin(), sl.rend());
+            int best = greedy(order);
+            vector<int> best_col = col;
+            for (int it = 0; it < 6; ++it) {  // iterated greedy: classes as blocks, largest colour index first
+                vector<int> ord2(order);
+                std::stable_sort(ord2.begin(), ord2.end(), [&](int x, int y) { return best_col[(size_t)x] > best_col[(size_t)y]; });
+                const int c2 = greedy(ord2);
+                if (c2 <= best) { best = c2; best_col = col; order = ord2; }
+                else col = best_col;
+            }
+            col = best_col;
         }
+        for (int k = 0; k < m; ++k)
+            if (relaxed[(size_t)k]) pcol[(size_t)idx[(size_t)(b + k)]] = col[(size_t)k];
+        int nc = 0;
+        for (int k = 0; k < m; ++k) nc = std::max(nc, col[(size_t)k] + 1);
+        tile_ncol[(size_t)t] = nc;
     });
+    if (std::getenv("MMG_VERBOSE") && nt > 0) {
+        long long sum = 0;
+        int mx = 0;
+        for (int c : tile_ncol) { sum += c; mx = std::max(mx, c); }
+        std::fprintf(stderr, "[mc_order_points] point colours per tile: mean %.1f, max %d (colouring %d)\n", (double)sum / nt, mx, point_colouring_);
+    }
 
     // ---- storage order --------------------------------------------------------------------
     st.reset(new mmgh::SetupTimer("mc_order_points: storage order"));
