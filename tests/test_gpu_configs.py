@@ -78,16 +78,19 @@ def test_neumann_cos_cos_known_answer_with_mean_shift(host):
     device, shift the solution to the manufactured mean, L1 error per point.  The reference holds no number
     for it; the bound is the discretisation error of a 49 x 49 cloud at polyDeg 3, which the CPU oracle on the
     same hierarchy must meet as well."""
-    # (seeds 12345+i: with the reference's defaults -- omega 1.4, restriction by interpolation -- the Neumann
-    # V-cycle does not contract on every jittered cloud, in the CPU oracle either: seeds 31+i diverge)
-    clouds = [host.square_cloud(n, seed=12345 + i) for i, n in enumerate([13, 25, 49])]
-    mg = host.Multigrid(clouds, [3, 3, 3], neumann=True, ordering=host.ORDER_MC, tile_points=128)
+    # Two levels: with the reference's defaults (omega 1.4, restriction by interpolation) the Neumann V-cycle
+    # contracts on every cloud tried as long as the coarsest grid is not much smaller than 25 x 25 -- slowly,
+    # 0.9 per cycle; a third level of 13 x 13 points (K = 25 stencils spanning a third of the domain) makes it
+    # diverge on most clouds, lattices included, in the CPU oracle exactly as on the device, and whether a lucky
+    # cloud still converges depends on the relaxation order.
+    clouds = [host.square_cloud(n, seed=12345 + i) for i, n in enumerate([25, 49])]
+    mg = host.Multigrid(clouds, [3, 3], neumann=True, ordering=host.ORDER_MC, tile_points=128)
     om = H.oracle_of_multigrid(mg)
     _follow_oracle(mg, om, 10)
-    mg.vcycles(60)
-    for _ in range(60):
+    mg.vcycles(170)
+    for _ in range(170):
         om.vcycle()
-    g = mg.grid(2)
+    g = mg.grid(1)
     xyz, _ = g.points()
     n = g.sizes()["n"]
     exact = np.cos(np.pi * xyz[:, 0]) * np.cos(np.pi * xyz[:, 1])
@@ -98,7 +101,7 @@ def test_neumann_cos_cos_known_answer_with_mean_shift(host):
 
     err_gpu, err_cpu = l1_after_shift(g.values()), l1_after_shift(om.levels[-1].x)
     assert mg.residuals[-1] < 1e-6
-    assert err_gpu < 5e-4, err_gpu           # measured 1.2e-4 (CPU oracle: the same)
+    assert err_gpu < 5e-4, err_gpu           # measured 1.1e-4 (CPU oracle: the same)
     assert abs(err_gpu - err_cpu) <= 1e-8 * max(err_cpu, 1e-12), (err_gpu, err_cpu)
 
 
