@@ -1974,7 +1974,23 @@ int rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud
         a.n_ops = n_ops;
         for (int o = 0; o < n_ops; ++o) a.ops[o] = ops[o];
         a.rbf_exp = rbf_exp;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool verbose = std::getenv("MMG_VERBOSE") != nullptr;
+        if (verbose) {
+            HIPC(hipEventCreate(&ev0));
+            HIPC(hipEventCreate(&ev1));
+            HIPC(hipEventRecord(ev0, g_stream));
+        }
         HIPC(launch_rbf_weights(a, (int)std::min<long long>(ne, 2LL * resident), lds, g_stream));
+        if (verbose) {
+            HIPC(hipEventRecord(ev1, g_stream));
+            HIPC(hipEventSynchronize(ev1));
+            float ms = 0;
+            HIPC(hipEventElapsedTime(&ms, ev0, ev1));
+            std::fprintf(stderr, "[setup]   rbf_weights_kernel: %lld stencils of %d x %d in %.1f ms\n", ne, stencil + pt, stencil + pt, ms);
+            (void)hipEventDestroy(ev0);
+            (void)hipEventDestroy(ev1);
+        }
         if (by_column && !nbr_in) {
             HIPC(launch_sort_rows(d_nbr.p, d_w.p, ne, stencil, n_ops, (int)std::min<long long>(ne, 128LL * cus), g_stream));
             if (nbr_out)

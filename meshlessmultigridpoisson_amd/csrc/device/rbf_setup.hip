@@ -42,6 +42,32 @@ __device__ __forceinline__ double wmin(double v)
     return v;
 }
 
+// (value, index) argmax step against the lane a DPP pattern pairs this lane with: larger value, then smaller index
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(double &best, int &bidx)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(best);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(0, bidx, CTRL, 0xf, 0xf, false);
+    const double ob = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+}
+// wave-wide: four DPP steps inside the rows of 16 lanes (a few cycles each), two LDS-crossbar shuffles across rows
+__device__ __forceinline__ void wave_argmax(double &best, int &bidx)
+{
+    argmax_dpp<0xB1>(best, bidx);   // quad_perm [1,0,3,2]
+    argmax_dpp<0x4E>(best, bidx);   // quad_perm [2,3,0,1]
+    argmax_dpp<0x141>(best, bidx);  // row_half_mirror
+    argmax_dpp<0x140>(best, bidx);  // row_mirror
+#pragma unroll
+    for (int msk = 16; msk <= 32; msk <<= 1) {
+        const double ob = __shfl_xor(best, msk, 64);
+        const int oi = __shfl_xor(bidx, msk, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+}
+
 // block-wide max / min of six values at once (bounding box); red: 6 * (NT / 64) doubles of LDS
 template <int NT>
 __device__ __forceinline__ void block_minmax(double &lox, double &hix, double &loy, double &hiy, double &loz, double &hiz, double *red)
@@ -155,7 +181,7 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
             }
             A[(size_t)j * ld + i] = v;
             const double av = fabs(v);
-            if (av > best) { best = av; bidx = idx; }
+            if (av > best) { best = av; bidx = 2 * idx + (v < 0.0 ? 1 : 0); }  // candidate index and its sign
         }
         // ---- right-hand sides (grid.cpp:312-331, :351-370, :389-413, :697-707) -------------
         // (entry `lane` of every right-hand side stays in a register until the coordinates may be overwritten)
@@ -213,27 +239,25 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
         // ---- full-pivot LU, in place ---------------------------------------------------------
         int rank = n;
         for (int k = 0; k < n; ++k) {
-            // wave argmax of (best, bidx): larger value first, then the smaller column-major index
-#pragma unroll
-            for (int msk = 32; msk >= 1; msk >>= 1) {
-                const double ob = __shfl_xor(best, msk, 64);
-                const int oi = __shfl_xor(bidx, msk, 64);
-                if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-            }
+            // argmax of (best, bidx): the largest value, among equals the smallest column-major index (bidx carries
+            // the sign of the candidate in its lowest bit)
+            wave_argmax(best, bidx);
             if (NT > 64) {  // ... and of the wavefronts
                 if ((lane & 63) == 0) { red[lane >> 6] = best; redi[lane >> 6] = bidx; }
                 __syncthreads();
-                best = red[0];
-                bidx = redi[0];
-                for (int w = 1; w < NT / 64; ++w) {
-                    const double ob = red[w];
-                    const int oi = redi[w];
-                    if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-                }
+                double mx = red[0];
+                for (int w = 1; w < NT / 64; ++w) mx = fmax(mx, red[w]);
+                int bi = 0x7fffffff;
+                for (int w = 0; w < NT / 64; ++w)
+                    if (red[w] == mx) bi = min(bi, redi[w]);
+                best = mx;
+                bidx = bi;
             }
             if (!(best > 0.0)) { rank = k; break; }
             const int m0 = n - k;                      // the search ran over the m0 x m0 trailing block
-            const int pc = k + bidx / m0, pr = k + (bidx - (bidx / m0) * m0);
+            const int pidx = bidx >> 1;
+            const double piv = (bidx & 1) ? -best : best;  // the pivot itself: |pivot| is what the search compared
+            const int pc = k + pidx / m0, pr = k + (pidx - (pidx / m0) * m0);
             if (pr != k) {
                 for (int j = lane; j < n; j += NT) {
                     const double t = A[(size_t)j * ld + k];
@@ -247,33 +271,63 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
                 }
             }
             __syncthreads();
-            if (pc != k) {
-                for (int i = lane; i < n; i += NT) {
-                    const double t = A[(size_t)k * ld + i];
-                    A[(size_t)k * ld + i] = A[(size_t)pc * ld + i];
-                    A[(size_t)pc * ld + i] = t;
+            // column swap and scaling of the pivot column in one pass
+            for (int i = lane; i < n; i += NT) {
+                double tk = A[(size_t)k * ld + i];
+                if (pc != k) {
+                    const double tp = A[(size_t)pc * ld + i];
+                    A[(size_t)pc * ld + i] = tk;
+                    tk = tp;
                 }
-                if (lane == 0) { const int t = cperm[k]; cperm[k] = cperm[pc]; cperm[pc] = t; }
+                if (i > k) tk /= piv;
+                if (pc != k || i > k) A[(size_t)k * ld + i] = tk;
             }
+            if (pc != k && lane == 0) { const int t = cperm[k]; cperm[k] = cperm[pc]; cperm[pc] = t; }
             __syncthreads();
-            const double piv = A[(size_t)k * ld + k];
             const int m = n - k - 1;
-            for (int i = lane; i < m; i += NT) A[(size_t)k * ld + k + 1 + i] /= piv;
-            __syncthreads();
             // rank-1 update of the trailing m x m block + search of the next pivot
             best = -1.0;
             bidx = 0x7fffffff;
             if (m > 0) {
-                const int sj = NT / m, si = NT - sj * m;
+                // Four elements per pass: their twelve LDS reads are requested before the first store (the compiler
+                // cannot know that the stores of one element never alias the loads of the next).  Measured with
+                // phases switched off (2.1e6 stencils of 70 x 70, 524 ms): this update 43 %, the skeleton of the
+                // 70 steps (pivot reduction, barriers) + assembly 42 %, solves 10 %, swaps 5 %; with four
+                // wavefronts per SIMD the update runs at the LDS's rate (16 eight-byte accesses per 4 elements).
+                // The update is bound by instruction issue (four wavefronts per SIMD): element offsets advance
+                // by additions only, all three operands of an element are addressed from one offset.
+                constexpr int U = 4;
+                const int sj = NT / m, si = NT - sj * m;   // a pass moves every thread on by NT elements
                 int j = lane / m, i = lane - j * m;
-                for (int idx = lane; idx < m * m; idx += NT) {
-                    double *col = A + (size_t)(k + 1 + j) * ld;
-                    const double v = col[k + 1 + i] - A[(size_t)k * ld + k + 1 + i] * col[k];
-                    col[k + 1 + i] = v;
-                    const double av = fabs(v);
-                    if (av > best) { best = av; bidx = idx; }
-                    i += si; j += sj;
-                    if (i >= m) { i -= m; ++j; }
+                int off = (k + 1 + j) * ld + (k + 1 + i);  // element (k+1+i, k+1+j)
+                const int dstep = sj * ld + si, dwrap = ld - m;
+                const int lrow = k * ld + k + 1;           // multipliers l_i = A[lrow + i]
+                const int safe = (k + 1) * ld + (k + 1);
+                const int cnt = (m * m - lane + NT - 1) / NT;  // elements of this thread
+                for (int q = 0; q < cnt; q += U) {
+                    double cv[U], lv[U], uv[U];
+                    int eo[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const bool ok = q + u < cnt;
+                        eo[u] = ok ? off : safe;
+                        const int iu = ok ? i : 0;
+                        cv[u] = A[eo[u]];
+                        lv[u] = A[lrow + iu];
+                        uv[u] = A[eo[u] - iu - 1];         // row k of the element's column
+                        i += si;
+                        off += dstep;
+                        if (i >= m) { i -= m; off += dwrap; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const double v = cv[u] - lv[u] * uv[u];
+                        if (q + u < cnt) {
+                            A[eo[u]] = v;
+                            const double av = fabs(v);
+                            if (av > best) { best = av; bidx = 2 * (lane + (q + u) * NT) + (v < 0.0 ? 1 : 0); }
+                        }
+                    }
                 }
             }
             __syncthreads();
