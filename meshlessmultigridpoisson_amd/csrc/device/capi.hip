@@ -1793,7 +1793,7 @@ struct KnnIndex {
         double cs = std::pow(vol * ppc / (double)n, 1.0 / dim);
         if (!(cs > 0) || !std::isfinite(cs)) cs = 1.0;
         const double cap = std::max(64.0, 4.0 * (double)n);  // degenerate extents: never more than 4 cells per point
-        for (;;) {
+        for (int it = 0;; ++it) {
             double total = 1.0;
             for (int a = 0; a < 3; ++a) {
                 const double m = a < dim ? std::floor((hi[a] - lo[a]) / cs) + 1.0 : 1.0;
@@ -1801,6 +1801,11 @@ struct KnnIndex {
                 cells.nc[a] = (int)std::min(m, 2.0e9);
             }
             if (total <= cap) break;
+            if (it > 4000 || !std::isfinite(total)) {  // non-finite coordinates: one cell, the search degenerates to a scan
+                cells.nc[0] = cells.nc[1] = cells.nc[2] = 1;
+                cs = 1.0;
+                break;
+            }
             cs *= 1.26;
         }
         for (int a = 0; a < 3; ++a) cells.lo[a] = lo[a];
