@@ -43,6 +43,7 @@ FractionalStepGrid::~FractionalStepGrid()
         for (VectorXd *x : {u, v, u_hat, v_hat, w, w_hat}) x->detach();
         mmg_fracstep_destroy(fs_);
     }
+    drop_op_cache();
     delete w;
     delete w_old;
     delete w_hat;
@@ -133,25 +134,43 @@ void FractionalStepGrid::set_uv_bound()
 Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 {
     const int n = laplaceMatSize_;
-    ensure_knn();
+    if (op_cache_version_ != geom_version_) drop_op_cache();
+    if (op_cache_[which]) {
+        SparseRowMajor *m = op_cache_[which];
+        op_cache_[which] = nullptr;
+        return m;
+    }
     {
-        // batched on the device when it pays (Grid::batched_stencils): kNN on the host threads, the dense
-        // solves on the MI355X; `which` maps to the operator ids 1 (d/dx), 2 (d/dy), 0 (Laplacian)
+        // batched on the device when it pays (Grid::batched_stencils): neighbour search and dense solves on the
+        // MI355X, all operators of the grid against ONE factorisation per point (operator ids 1 d/dx, 2 d/dy,
+        // 3 d/dz, 0 Laplacian), rows returned in ascending column order = the CSR arrays themselves
         vector<char> isb((size_t)n);
         for (int i = 0; i < n; ++i) isb[(size_t)i] = bcFlags_[(size_t)i] != 0;
         mmgh::RawVec<int> nbr;
         mmgh::RawVec<double> w;
         const int ss = stencilSizeFor(properties_.polyDeg, dim_);
-        if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, {which == 0 ? 1 : (which == 1 ? 2 : (which == 3 ? 3 : 0))}, nbr, w)) {
-            vector<Triplet> trip;
-            trip.reserve((size_t)n * (size_t)ss);
-            for (int i = 0; i < n; ++i)
-                for (int j = 0; j < ss; ++j) trip.emplace_back(i, nbr[(size_t)i * ss + j], w[(size_t)i * ss + j]);
-            SparseRowMajor *m = new SparseRowMajor(n, n, true);
-            m->setFromTriplets(trip.begin(), trip.end());
+        const vector<int> whichs = dim_ >= 3 ? vector<int>{0, 1, 3, 2} : vector<int>{0, 1, 2};
+        vector<int> ops;
+        for (int wch : whichs) ops.push_back(wch == 0 ? 1 : (wch == 1 ? 2 : (wch == 3 ? 3 : 0)));
+        if (batched_stencils(points_, &isb, neumannFlag_, properties_.polyDeg, ops, nbr, w, true)) {
+            drop_op_cache();
+            const size_t per = (size_t)n * (size_t)ss;
+            for (size_t o = 0; o < whichs.size(); ++o) {
+                std::vector<int> outer((size_t)n + 1);
+                for (int i = 0; i <= n; ++i) outer[(size_t)i] = i * ss;
+                mmgh::RawVec<int> inner(nbr.begin(), nbr.end());
+                mmgh::RawVec<double> val(w.begin() + (long)(o * per), w.begin() + (long)((o + 1) * per));
+                SparseRowMajor *m = new SparseRowMajor(n, n, true);
+                m->adopt(std::move(outer), std::move(inner), std::move(val));
+                op_cache_[whichs[o]] = m;
+            }
+            op_cache_version_ = geom_version_;
+            SparseRowMajor *m = op_cache_[which];
+            op_cache_[which] = nullptr;
             return m;
         }
     }
+    ensure_knn();
     std::vector<std::vector<double>> W((size_t)n);
     std::vector<vector<int>> NB((size_t)n);
     std::atomic<int> next{0};
@@ -176,6 +195,12 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
     SparseRowMajor *m = new SparseRowMajor(n, n, true);
     m->setFromTriplets(trip.begin(), trip.end());
     return m;
+}
+
+void FractionalStepGrid::drop_op_cache()
+{
+    for (auto &m : op_cache_) { delete m; m = nullptr; }
+    op_cache_version_ = -1;
 }
 
 void FractionalStepGrid::build_derivX_mat() { delete derivXMat_; derivXMat_ = build_op(0); }

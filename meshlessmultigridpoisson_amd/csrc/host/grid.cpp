@@ -826,6 +826,7 @@ void Grid::apply_order(const vector<int> &order)
     const size_t n = points_.size();
     if (order.size() != n) throw std::invalid_argument("apply_order: permutation size mismatch");
     invalidate_device();
+    ++geom_version_;
     vector<Point> np(n), nn(n);
     vector<int> nf(n), old2new(n);
     std::vector<double> &src = source_.host_mut();

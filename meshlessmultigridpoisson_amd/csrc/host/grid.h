@@ -58,6 +58,7 @@ public:
     int tile_size_ = 0;
     int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy
     int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
+    int geom_version_ = 0;       // bumped by apply_order: caches keyed on the point order compare it
     int point_colouring_ = 1;    // mc_order_points, points of a tile: 0 greedy in tile order, 1 smallest-last + iterated greedy
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring")
     int setup_threads_ = 0;      // 0 = hardware concurrency
