@@ -187,6 +187,28 @@ def rbf_weights(dim, polydeg, rbf_exp, cloud_xyz, eval_xyz, nbr, ops):
     return out
 
 
+def rbf_stencils(dim, polydeg, rbf_exp, stencil, cloud_xyz, eval_xyz, ops, cloud_flag=None, eval_flag=None, by_column=False):
+    """mmg_rbf_stencils: neighbour search + weights in one call.  Returns (nbr [n_eval][stencil], weights
+    [n_ops][n_eval][stencil], short_rows); rows nearest first, or in ascending neighbour id with by_column."""
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float64).reshape(-1, 3)
+    ev = np.ascontiguousarray(eval_xyz, dtype=np.float64).reshape(-1, 3)
+    cf = None if cloud_flag is None else np.ascontiguousarray(cloud_flag, dtype=np.uint8)
+    qf = None if eval_flag is None else np.ascontiguousarray(eval_flag, dtype=np.uint8)
+    op = np.ascontiguousarray(ops, dtype=np.int32)
+    nbr = np.zeros((ev.shape[0], int(stencil)), dtype=np.int32)
+    w = np.zeros((len(op), ev.shape[0], int(stencil)))
+    short = C.c_int(0)
+    f = lib().mmg_rbf_stencils
+    _bp = C.POINTER(C.c_ubyte)
+    f.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _bp, C.c_longlong, _dp, _bp, C.c_int, _ip, C.c_int, _ip, _dp,
+                  C.POINTER(C.c_int)]
+    check(f(dim, polydeg, float(rbf_exp), int(stencil), cloud.shape[0], cloud.ctypes.data_as(_dp),
+            cf.ctypes.data_as(_bp) if cf is not None else None, ev.shape[0], ev.ctypes.data_as(_dp),
+            qf.ctypes.data_as(_bp) if qf is not None else None, len(op), op.ctypes.data_as(_ip), 1 if by_column else 0,
+            nbr.ctypes.data_as(_ip), w.ctypes.data_as(_dp), C.byref(short)))
+    return nbr, w, short.value
+
+
 def knn(dim, cloud_xyz, query_xyz, k, cloud_flag=None, query_flag=None):
     """mmg_knn: indices of the k smallest (distance, index) pairs per query, [n_query][k] (-1 = cloud ran out)."""
     cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float64).reshape(-1, 3)

@@ -268,3 +268,34 @@ def test_device_knn_matches_setup_oracle_and_clustered_cloud(host):
     cloud[1000:] = 0.5 + 0.01 * rng.standard_normal((5000, 3))
     q = np.concatenate([cloud[:150], cloud[1000:1150]])
     assert np.array_equal(_capi.knn(3, cloud, q, 50), _brute_knn(cloud, q, 50, 3))
+
+
+@pytest.mark.parametrize("dim,n,deg", [(2, 2500, 3), (3, 3375, 3)])
+def test_rbf_stencils_is_search_plus_weights_and_orders_rows(host, dim, n, deg):
+    """mmg_rbf_stencils through the C-ABI: (a) its lists are mmg_knn's, its weights those of mmg_rbf_weights on these
+    lists, bit for bit (same kernels, the lists just never leave the device); (b) by_column returns every row as the
+    same (id, weight) pairs in ascending id -- the order of a CSR row; (c) flags follow mmg_knn's Neumann rule;
+    (d) a cloud smaller than the stencil reports short rows instead of weights."""
+    from meshlessmultigridpoisson_amd import _capi
+    m = int(round(n ** (1.0 / dim)))
+    pts = host.box_cloud(m, dim, seed=3)
+    ss = host.stencil_size(deg, dim)
+    ops = [0, 1, 2] + ([3] if dim == 3 else [])
+    nbr, w, short = _capi.rbf_stencils(dim, deg, 3.0, ss, pts, pts, ops)
+    assert short == 0
+    assert np.array_equal(nbr, _capi.knn(dim, pts, pts, ss))
+    assert np.array_equal(w, _capi.rbf_weights(dim, deg, 3.0, pts, pts, nbr, ops))
+    nbr_c, w_c, short = _capi.rbf_stencils(dim, deg, 3.0, ss, pts, pts, ops, by_column=True)
+    assert short == 0
+    order = np.argsort(nbr, axis=1, kind="stable")
+    assert np.array_equal(nbr_c, np.take_along_axis(nbr, order, axis=1))
+    for o in range(len(ops)):
+        assert np.array_equal(w_c[o], np.take_along_axis(w[o], order, axis=1))
+    flag = (np.abs(pts[:, :dim] - 0.5).max(axis=1) == 0.5).astype(np.uint8)      # the boundary of the box
+    nbr_f, _w, short = _capi.rbf_stencils(dim, deg, 3.0, ss, pts, pts, [0], cloud_flag=flag, eval_flag=flag)
+    assert short == 0 and np.array_equal(nbr_f, _capi.knn(dim, pts, pts, ss, flag, flag))
+    b = np.flatnonzero(flag)
+    assert all(flag[nbr_f[i, 1:]].sum() == 0 for i in b[:50])                     # only itself among the boundary points
+    few = pts[: ss - 1]
+    _n, _w2, short = _capi.rbf_stencils(dim, deg, 3.0, ss, few, few, [0])
+    assert short == len(few)
