@@ -237,3 +237,23 @@ def test_vcycle_body_as_hip_graph_changes_no_bit():
     finally:
         _capi.set_option("vcycle_graph", 0)
 
+
+
+@pytest.mark.parametrize("dim,sides,degs", [(2, [25, 49], [5, 5]), (2, [25, 49], [6, 6]), (2, [31, 61, 121], [3, 4, 5]),
+                                            (3, [9, 17], [2, 2]), (3, [11, 21], [4, 4])])
+def test_vcycle_follows_oracle_at_every_polynomial_degree(host, dim, sides, degs):
+    """The reference's polynomial degrees beyond the headline ones (grid.cpp:266-267: K = int(2.5 polyTerms): 2-D
+    L = 5 -> 52, L = 6 -> 70; 3-D L = 2 -> 25, L = 4 -> 87): long rows take other code paths (wider lanes per row, the
+    packed stream instead of the dense groups, a 122 x 122 stencil system in one CU's LDS), mixed degrees make the
+    interpolation stencils (K of the finest degree, multigrid.cpp:22,25) differ from the level operators'.  Device
+    setup and V-cycles vs the CPU oracle on the same hierarchy."""
+    cloud = (lambda n, s: host.square_cloud(n, seed=s)) if dim == 2 else (lambda n, s: host.box_cloud(n, 3, seed=s))
+    clouds = [cloud(n, 4321 + i) for i, n in enumerate(sides)]
+    host.set_option("device_setup", 1)
+    try:
+        mg = host.Multigrid(clouds, degs, dim=dim, neumann=False, ordering=host.ORDER_MC, tile_points=0)
+    finally:
+        host.set_option("device_setup", -1)
+    om = H.oracle_of_multigrid(mg)
+    _follow_oracle(mg, om, 6)
+    assert H.rel_err(mg.grid(len(sides) - 1).values(), om.levels[-1].x) < 1e-9
