@@ -299,3 +299,21 @@ def test_rbf_stencils_is_search_plus_weights_and_orders_rows(host, dim, n, deg):
     few = pts[: ss - 1]
     _n, _w2, short = _capi.rbf_stencils(dim, deg, 3.0, ss, few, few, [0])
     assert short == len(few)
+
+
+def test_knn_edge_cases(host):
+    """Empty query set, a cloud of one point, k = 1, the largest supported k (256), k beyond it (refused), duplicate
+    points (distance 0 ties resolved by index)."""
+    from meshlessmultigridpoisson_amd import _capi
+    rng = np.random.default_rng(0)
+    cloud = np.zeros((700, 3))
+    cloud[:, :2] = rng.uniform(0, 1, (700, 2))
+    assert _capi.knn(2, cloud, np.zeros((0, 3)), 5).shape == (0, 5)
+    one = _capi.knn(2, cloud[:1], cloud[:4], 3)
+    assert np.array_equal(one, np.tile(np.array([0, -1, -1], dtype=np.int32), (4, 1)))
+    assert np.array_equal(_capi.knn(2, cloud, cloud, 1)[:, 0], np.arange(700))
+    assert np.array_equal(_capi.knn(2, cloud, cloud[:40], 256), _brute_knn(cloud, cloud[:40], 256, 2))
+    with pytest.raises(Exception):
+        _capi.knn(2, cloud, cloud[:4], 257)
+    dup = np.concatenate([cloud[:50], cloud[:50], cloud[50:300]])       # every one of the first 50 points twice
+    assert np.array_equal(_capi.knn(2, dup, dup[:100], 9), _brute_knn(dup, dup[:100], 9, 2))
