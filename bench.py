@@ -475,7 +475,7 @@ def main():
             "config": {
                 "workload": wl + f", K={stencil} "
                             f"kNN stencils ({'RBF-FD Laplacian, PHS r^3 + degree-' + str(a.polydeg) + ' polynomials' if a.operator == 'rbf' else 'graph-Laplacian values on the RBF-FD sparsity'}), Dirichlet, "
-                            f"one SOR sweep per step" + ("" if strong else " (BASELINE configs[2])"),
+                            f"one SOR sweep per step" + (" (BASELINE configs[2])" if not strong and a.dim == 3 and a.nside == 216 else ""),
                 "points_per_gpu": int(n_owned), "interior_points_per_gpu": int(interior), "stencil": stencil,
                 "ordering": "mc_order_points", "tile_points": int(round(n_owned / max(1, info["n_tiles"]))), "tiles": info["n_tiles"],
                 "phases_per_sweep": info["n_phases"], "lanes_per_row": info["lanes_per_row"],
