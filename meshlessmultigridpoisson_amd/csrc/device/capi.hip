@@ -291,6 +291,7 @@ struct mmg_level {
     DevBuf<int32_t> send_idx;
     DevBuf<double> sendbuf;
     DevBuf<double> scalS;  // all-reduced sum of the non-Neumann x (multiplier row)
+    double mult_row = 1.0;  // uniform off-diagonal entry of the multiplier row (the reference: 1; 3-D hierarchies scale it)
     // Grid::push_inhomog_to_rhs (mmg_level_set_neumann_coupling): interior-row entries in Neumann columns
     PlanGpu C;
     DevBuf<double> c_diag, c_s, c_t;
@@ -533,9 +534,9 @@ int sweep_some(mmg_level *lv, int k, int *done)
             HIPC(launch_sum_partials(lv->partX.p, lv->A.n_tiles, lv->scalS.p, g_stream));
             int rc = allreduce_sum(lv->scalS.p, 1);
             if (rc) return rc;
-            HIPC(launch_mult_apply(lv->x.p, lv->b.p, lv->n, lv->scalS.p, lv->omega, g_stream));
-        } else if (lv->A.exact) HIPC(launch_mult_update_exact(lv->x.p, lv->b.p, lv->n, lv->flags8.p, lv->omega, g_stream));
-        else HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, g_stream));
+            HIPC(launch_mult_apply(lv->x.p, lv->b.p, lv->n, lv->scalS.p, lv->omega, lv->mult_row, g_stream));
+        } else if (lv->A.exact) HIPC(launch_mult_update_exact(lv->x.p, lv->b.p, lv->n, lv->flags8.p, lv->omega, lv->mult_row, g_stream));
+        else HIPC(launch_mult_update(lv->x.p, lv->b.p, lv->n, lv->partX.p, lv->A.n_tiles, lv->omega, lv->mult_row, g_stream));
     }
     return MMG_OK;
 }
@@ -678,13 +679,13 @@ int residual_dev(mmg_level *lv, bool norms)
         if (rc) return rc;
         HIPC(launch_resid_finalize_dist(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
                                         lv->partBn.p, norms ? lv->n_absb : 0, lv->scalS.p, lv->x.p, lv->b.p, lv->r.p,
-                                        lv->n, lv->neumann, g_rccl.rank == 0, lv->scal.p, g_stream));
+                                        lv->n, lv->neumann, g_rccl.rank == 0, lv->scal.p, lv->mult_row, g_stream));
     } else
     HIPC(launch_resid_finalize(lv->partA.p, lv->A.n_tiles, lv->partB.p, lv->B.empty() ? 0 : lv->B.n_tiles,
                                lv->partBn.p, norms ? lv->n_absb : 0, lv->partX.p, lv->A.n_tiles, lv->x.p, lv->b.p,
-                               lv->r.p, lv->n, lv->neumann, lv->scal.p, g_stream));
+                               lv->r.p, lv->n, lv->neumann, lv->scal.p, lv->mult_row, g_stream));
     if (lv->A.exact)  // reference's summation order for the multiplier-row residual and both norms
-        HIPC(launch_norms_exact(lv->r.p, lv->b.p, lv->x.p, lv->flags8.p, lv->n, lv->neumann, lv->a_size, lv->scal.p, g_stream));
+        HIPC(launch_norms_exact(lv->r.p, lv->b.p, lv->x.p, lv->flags8.p, lv->n, lv->neumann, lv->a_size, lv->scal.p, lv->mult_row, g_stream));
     if (lv->distributed && g_rccl.comm && g_rccl.nranks > 1)
         NCCLC(g_rccl.AllReduce(lv->scal.p, lv->scal.p, 2, kNcclDouble, kNcclSum, g_rccl.comm, g_stream));
     return MMG_OK;
@@ -1172,7 +1173,7 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     lv->iters = d->iters;
 
     {
-        const std::string merr = check_multiplier(*d);
+        const std::string merr = check_multiplier(*d, &lv->mult_row);
         if (!merr.empty()) return fail(MMG_ERR_UNSUPPORTED, merr);
     }
     // ---- boundaries: deduplicated scatter lists, last writer wins (sequential semantics)

@@ -681,13 +681,13 @@ __global__ __launch_bounds__(64) void tile_kernel_exact(TileArgs a)
 }
 
 // multiplier row in the reference's order: -(x_0 + x_1 + ...) over non-Neumann points, ascending
-__global__ void k_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega)
+__global__ void k_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, double mrow)
 {
 #pragma clang fp contract(off)
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     double s = 0.0;
     for (int i = 0; i < n; ++i)
-        if (flags8[i] < 2) s = s + x[i];
+        if (flags8[i] < 2) s = s + mrow * x[i];  // mrow: the uniform entry of the multiplier row (the reference: 1)
     double xi = b[n] - s;
     xi = xi * (omega / 1.0);
     const double keep = (1.0 - omega) * x[n];
@@ -698,14 +698,14 @@ __global__ void k_mult_update_exact(double *x, const double *b, int n, const uin
 // Eigen lpNorm<1>: sequential; with a multiplier row (neumann) r[n] is first recomputed in
 // the reference's order: b_N - (x_0 + x_1 + ... + x_N)
 __global__ void k_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
-                              int a_size, double *out2)
+                              int a_size, double *out2, double mrow)
 {
 #pragma clang fp contract(off)
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     if (neumann) {
         double s = 0.0;
         for (int i = 0; i < n; ++i)
-            if (flags8[i] < 2) s = s + x[i];
+            if (flags8[i] < 2) s = s + mrow * x[i];
         s = s + x[n];
         r[n] = b[n] - s;
     }
@@ -761,22 +761,22 @@ __device__ double block_sum_256(const double *v, int n, double *sh)
 }
 
 __global__ __launch_bounds__(256) void k_mult_update(double *x, const double *b, int n, const double *partial,
-                                                     int n_partial, double omega)
+                                                     int n_partial, double omega, double mrow)
 {
     __shared__ double sh[256];
     const double S = block_sum_256(partial, n_partial, sh);
     if (threadIdx.x == 0) {
-        double xi = b[n] - S;          // a_NN = 1 (grid.cpp:570-576)
+        double xi = b[n] - mrow * S;   // a_NN = 1 (grid.cpp:570-576); a_Nj = mrow (the reference: 1)
         xi *= omega / 1.0;
         xi += (1.0 - omega) * x[n];
         x[n] = xi;
     }
 }
 
-__global__ void k_mult_apply(double *x, const double *b, int n, const double *S, double omega)
+__global__ void k_mult_apply(double *x, const double *b, int n, const double *S, double omega, double mrow)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    double xi = b[n] - *S;
+    double xi = b[n] - mrow * *S;
     xi *= omega / 1.0;
     xi += (1.0 - omega) * x[n];
     x[n] = xi;
@@ -785,7 +785,7 @@ __global__ void k_mult_apply(double *x, const double *b, int n, const double *S,
 __global__ __launch_bounds__(256) void k_resid_finalize_dist(const double *pa, int na, const double *pb, int nb,
                                                              const double *pbn, int nbn, const double *S, const double *x,
                                                              const double *b, double *r, int n, int neumann,
-                                                             int count_shared, double *out2)
+                                                             int count_shared, double *out2, double mrow)
 {
     __shared__ double sh[256];
     double nr = block_sum_256(pa, na, sh);
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_resid_finalize_dist(const double *pa, i
     double nbsum = block_sum_256(pbn, nbn, sh);
     if (threadIdx.x == 0) {
         if (neumann) {
-            const double rn = b[n] - (*S + x[n]);
+            const double rn = b[n] - (mrow * *S + x[n]);
             r[n] = rn;
             if (count_shared) nr += fabs(rn);
             else if (nbn > 0) nbsum -= fabs(b[n]);  // the replicated multiplier entry counts once
@@ -806,17 +806,17 @@ __global__ __launch_bounds__(256) void k_resid_finalize_dist(const double *pa, i
 constexpr int kAbsBlock = 256;
 constexpr int kAbsPerBlock = 256 * 16;
 }  // namespace
-hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, hipStream_t s)
+hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, double mrow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mult_apply, dim3(1), dim3(64), 0, s, x, b, n, S, omega);
+    hipLaunchKernelGGL(k_mult_apply, dim3(1), dim3(64), 0, s, x, b, n, S, omega, mrow);
     return hipGetLastError();
 }
 hipError_t launch_resid_finalize_dist(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
                                       const double *S, const double *x, const double *b, double *r, int n, int neumann,
-                                      int count_shared, double *out2, hipStream_t s)
+                                      int count_shared, double *out2, double mrow, hipStream_t s)
 {
     hipLaunchKernelGGL(k_resid_finalize_dist, dim3(1), dim3(256), 0, s, pa, na, pb, nb, pbn, nbn, S, x, b, r, n, neumann,
-                       count_shared, out2);
+                       count_shared, out2, mrow);
     return hipGetLastError();
 }
 int abs_sum_blocks(long long n) { return (int)((n + kAbsPerBlock - 1) / kAbsPerBlock); }
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void k_abs_sum(const double *v, long long n, d
 __global__ __launch_bounds__(256) void k_resid_finalize(const double *pa, int na, const double *pb, int nb,
                                                         const double *pbn, int nbn, const double *px, int npx,
                                                         const double *x, const double *b, double *r, int n,
-                                                        int neumann, double *out2)
+                                                        int neumann, double *out2, double mrow)
 {
     __shared__ double sh[256];
     double nr = block_sum_256(pa, na, sh);
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256) void k_resid_finalize(const double *pa, int na
     if (neumann) S = block_sum_256(px, npx, sh);
     if (threadIdx.x == 0) {
         if (neumann) {
-            const double rn = b[n] - (S + x[n]);  // multiplier row (grid.cpp:570-576)
+            const double rn = b[n] - (mrow * S + x[n]);  // multiplier row (grid.cpp:570-576)
             r[n] = rn;
             nr += fabs(rn);
         }
@@ -1163,15 +1163,15 @@ hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_
     }
     return hipGetLastError();
 }
-hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, hipStream_t s)
+hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, double mrow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mult_update_exact, dim3(1), dim3(64), 0, s, x, b, n, flags8, omega);
+    hipLaunchKernelGGL(k_mult_update_exact, dim3(1), dim3(64), 0, s, x, b, n, flags8, omega, mrow);
     return hipGetLastError();
 }
 hipError_t launch_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
-                              int a_size, double *out2, hipStream_t s)
+                              int a_size, double *out2, double mrow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_norms_exact, dim3(1), dim3(64), 0, s, r, b, x, flags8, n, neumann, a_size, out2);
+    hipLaunchKernelGGL(k_norms_exact, dim3(1), dim3(64), 0, s, r, b, x, flags8, n, neumann, a_size, out2, mrow);
     return hipGetLastError();
 }
 
@@ -1223,9 +1223,9 @@ hipError_t launch_scatter_vals_masked(double *v, const int32_t *idx, const doubl
     return hipGetLastError();
 }
 hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial, double omega,
-                              hipStream_t s)
+                              double mrow, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mult_update, dim3(1), dim3(256), 0, s, x, b, n, partial, n_partial, omega);
+    hipLaunchKernelGGL(k_mult_update, dim3(1), dim3(256), 0, s, x, b, n, partial, n_partial, omega, mrow);
     return hipGetLastError();
 }
 
@@ -1237,10 +1237,10 @@ hipError_t launch_abs_sum(const double *v, long long n, double *partial, hipStre
 }
 hipError_t launch_resid_finalize(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
                                  const double *px, int npx, const double *x, const double *b, double *r, int n,
-                                 int neumann, double *out2, hipStream_t s)
+                                 int neumann, double *out2, double mrow, hipStream_t s)
 {
     hipLaunchKernelGGL(k_resid_finalize, dim3(1), dim3(256), 0, s, pa, na, pb, nb, pbn, nbn, px, npx, x, b, r, n,
-                       neumann, out2);
+                       neumann, out2, mrow);
     return hipGetLastError();
 }
 

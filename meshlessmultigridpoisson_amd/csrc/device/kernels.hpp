@@ -74,9 +74,10 @@ hipError_t launch_sweep_resident(const TileArgs &a, hipStream_t s);
 // exact-arithmetic variant (plans built with exact = true, L = 1): every row is accumulated by
 // one lane in the reference's stored order with separately rounded multiply and add
 hipError_t launch_tile_kernel_exact(TileMode mode, const TileArgs &a, hipStream_t s);
-hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, hipStream_t s);
+// mrow (here and below): the uniform off-diagonal entry of the multiplier row (the reference: 1)
+hipError_t launch_mult_update_exact(double *x, const double *b, int n, const uint8_t *flags8, double omega, double mrow, hipStream_t s);
 hipError_t launch_norms_exact(double *r, const double *b, const double *x, const uint8_t *flags8, int n, int neumann,
-                              int a_size, double *out2, hipStream_t s);
+                              int a_size, double *out2, double mrow, hipStream_t s);
 
 // ---- dense plans (PlanDev::dense): workgroups of PlanDev::waves wavefronts per tile (kernels_mw.hip) ----
 // one phase of a sweep (MODE_SOR) or the residual (MODE_RESID)
@@ -98,23 +99,23 @@ hipError_t launch_gather(double *dst, const double *src, const int32_t *idx, int
 hipError_t launch_scatter_const(double *v, const int32_t *idx, int n, double c, hipStream_t s);
 hipError_t launch_scatter_vals(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);
 hipError_t launch_scatter_vals_masked(double *v, const int32_t *idx, const double *vals, int n, hipStream_t s);  // idx < 0: skipped
-// x[n] <- (1-w) x[n] + w (b[n] - sum(partial))            (grid.cpp:118-141, row N)
+// x[n] <- (1-w) x[n] + w (b[n] - mrow * sum(partial))     (grid.cpp:118-141, row N)
 hipError_t launch_mult_update(double *x, const double *b, int n, const double *partial, int n_partial,
-                              double omega, hipStream_t s);
+                              double omega, double mrow, hipStream_t s);
 // x[n] <- (1-w) x[n] + w (b[n] - *S)   (distributed: *S is the all-reduced sum)
-hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, hipStream_t s);
+hipError_t launch_mult_apply(double *x, const double *b, int n, const double *S, double omega, double mrow, hipStream_t s);
 // distributed variant of launch_resid_finalize: S is the all-reduced sum of the non-Neumann x;
 // only `count_shared` ranks (rank 0) add the multiplier row and b[n] to the norms
 hipError_t launch_resid_finalize_dist(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
                                       const double *S, const double *x, const double *b, double *r, int n, int neumann,
-                                      int count_shared, double *out2, hipStream_t s);
+                                      int count_shared, double *out2, double mrow, hipStream_t s);
 // partial[block] = sum |v|
 int abs_sum_blocks(long long n);
 hipError_t launch_abs_sum(const double *v, long long n, double *partial, hipStream_t s);
 // out2[0] = sum(pa)+sum(pb)+|r_N| ; out2[1] = sum(pbn) ; writes r[n] when neumann
 hipError_t launch_resid_finalize(const double *pa, int na, const double *pb, int nb, const double *pbn, int nbn,
                                  const double *px, int npx, const double *x, const double *b, double *r, int n,
-                                 int neumann, double *out2, hipStream_t s);
+                                 int neumann, double *out2, double mrow, hipStream_t s);
 
 // ---- fractional-step pointwise kernels (fractionalStepGrid.cpp:101-154) -------------------
 // w_hat = w + dt * (-(u*wx + v*wy) + mu/rho * lap)

@@ -180,15 +180,26 @@ std::string build_boundary_lists(const mmg_level_desc &d, BoundaryLists *out)
     return std::string();
 }
 
-std::string check_multiplier(const mmg_level_desc &d)
+std::string check_multiplier(const mmg_level_desc &d, double *row_value)
 {
+    if (row_value) *row_value = 1.0;
     if (!d.neumann_flag) return std::string();
     const int n = d.n;
+    // the reference's row of ones (grid.cpp:570-576), or ONE other positive value on every off-diagonal entry (3-D
+    // hierarchies scale the row); the diagonal a_NN stays 1
+    double rv = 0.0;
     for (int p = d.rowptr[n]; p < d.rowptr[n + 1]; ++p) {
         const int c = d.col[p];
         const bool expect = (c == n) || (c >= 0 && c < n && d.bcflags[c] != 2);
-        if (d.val[p] != 1.0 || !expect) return "multiplier row is not the reference's row of ones";
+        if (!expect) return "multiplier row is not the reference's row over the non-Neumann points";
+        if (c == n) {
+            if (d.val[p] != 1.0) return "multiplier row: diagonal entry is not 1";
+            continue;
+        }
+        if (rv == 0.0) rv = d.val[p];
+        if (!(d.val[p] > 0.0) || d.val[p] != rv) return "multiplier row is not one positive value on every entry";
     }
+    if (row_value && rv != 0.0) *row_value = rv;
     int cnt = 0;
     for (int i = 0; i < n; ++i) cnt += d.bcflags[i] != 2;
     if (d.rowptr[n + 1] - d.rowptr[n] != cnt + 1) return "multiplier row does not cover every non-Neumann point";

@@ -44,7 +44,7 @@ struct BoundaryLists {
 std::string build_boundary_lists(const mmg_level_desc &d, BoundaryLists *out);
 
 // Checks the reference's multiplier row/column structure (grid.cpp:566-576).
-std::string check_multiplier(const mmg_level_desc &d);
+std::string check_multiplier(const mmg_level_desc &d, double *row_value = nullptr);
 
 void csc_to_csr(int rows, int cols, const int *colptr, const int *rowidx, const double *val,
                 std::vector<int> *rowptr, std::vector<int> *col, std::vector<double> *rval);

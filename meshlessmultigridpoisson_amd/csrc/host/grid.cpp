@@ -328,6 +328,19 @@ void Grid::build_deriv_normal_bound()
     });
 }
 
+// Off-diagonal entries of the multiplier row (grid.cpp:570-576: 1).  Relaxing the bordered system couples the mean of
+// x and the multiplier with strength n / |a_ii| per sweep: n h^2 / c, which is O(1) in 2-D but grows like the number
+// of points per side in 3-D -- the constant mode then explodes (measured: x uniformly large, multiplier 1e8 after five
+// cycles of a 27^3 hierarchy).  In 3-D the row is therefore scaled by 1 / n^(1/3): the same balance as in 2-D.  With
+// mu = s * lambda the scaled system [A, s 1; s 1^T, 1] is the same iteration as [A, 1; s^2 1^T, 1]: the COLUMN keeps
+// the reference's ones, only the row changes.
+double Grid::multiplier_row_value() const
+{
+    if (multRow_ > 0.0) return multRow_;
+    if (dim_ < 3) return 1.0;
+    return 1.0 / std::cbrt((double)std::max<size_t>(1, points_.size()));
+}
+
 int Grid::default_device_setup = -1;
 int Grid::default_point_colouring = 1;
 
@@ -569,8 +582,9 @@ void Grid::build_laplacian()
         std::vector<double>().swap(W[(size_t)i]);
     }
     if (neumannFlag_) {
+        const double mrow = multiplier_row_value();  // 1 in 2-D (the reference), scaled in 3-D
         for (int i = 0; i < n + 1; ++i)
-            if (i == n || bcFlags_[(size_t)i] != 2) trip.emplace_back(n, i, 1.0);
+            if (i == n || bcFlags_[(size_t)i] != 2) trip.emplace_back(n, i, i == n ? 1.0 : mrow);
         for (const deriv_normal_bc &b : deriv_normal_coeffs_)
             for (size_t j = 0; j < b.neighbors.size(); ++j) {
                 trip.emplace_back(b.pointID, b.neighbors[j], b.weights.coeff((long)j));
@@ -777,8 +791,10 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<in
     }
     for (int k = no; k < nl; ++k) outer[(size_t)k + 1] = outer[(size_t)k];
     if (neumannFlag_) {
+        const double mrow = multiplier_row_value();  // the GLOBAL grid's value on every rank
+        g->multRow_ = mrow;
         for (int k = 0; k < nl; ++k)
-            if (g->bcFlags_[(size_t)k] != 2) { inner.push_back(k); v.push_back(1.0); }
+            if (g->bcFlags_[(size_t)k] != 2) { inner.push_back(k); v.push_back(mrow); }
         inner.push_back(nl);
         v.push_back(1.0);
         outer[(size_t)nl + 1] = (int)inner.size();

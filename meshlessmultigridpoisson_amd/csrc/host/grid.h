@@ -58,6 +58,8 @@ public:
     int tile_size_ = 0;
     int tiling_ = 0;             // mc_order_points: 0 Cartesian slab tiles + parity colours, 1 kd-tree + greedy
     int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
+    double multRow_ = -1.0;      // off-diagonal value of the Neumann multiplier row; <= 0: 1 in 2-D, n^(-1/3) in 3-D
+    double multiplier_row_value() const;
     int geom_version_ = 0;       // bumped by apply_order: caches keyed on the point order compare it
     int point_colouring_ = 1;    // mc_order_points, points of a tile: 0 greedy in tile order, 1 smallest-last + iterated greedy
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring")

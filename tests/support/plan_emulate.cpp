@@ -25,6 +25,7 @@ enum { M_SOR, M_BOUND, M_RESID, M_SET, M_ADD };
 
 struct Emu {
     int n = 0, a_size = 0, neumann = 0;
+    double mult_row = 1.0;  // uniform off-diagonal entry of the multiplier row (check_multiplier)
     Plan A, B;
     BoundaryLists bl;
     std::vector<uint8_t> flags;
@@ -219,7 +220,7 @@ void *emu_level_create(const mmg_level_desc *d)
     e->a_size = d->a_size;
     e->neumann = d->neumann_flag ? 1 : 0;
     const int L = d->lanes_per_row > 0 ? d->lanes_per_row : 4;
-    std::string err = check_multiplier(*d);
+    std::string err = check_multiplier(*d, &e->mult_row);
     if (err.empty()) err = build_boundary_lists(*d, &e->bl);
     if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits, d->waves_per_tile > 1 ? d->waves_per_tile : 1);
     if (err.empty() && !e->bl.neu_rows.empty()) {
@@ -265,7 +266,7 @@ void emu_level_sweeps(void *h, double *x, const double *b, double omega, int nsw
             double S = 0.0;
             for (int i = 0; i < e->n; ++i)
                 if (e->flags[i] < 2) S += x[i];
-            double xi = b[e->n] - S;
+            double xi = b[e->n] - e->mult_row * S;
             xi *= omega / 1.0;
             xi += (1.0 - omega) * x[e->n];
             x[e->n] = xi;
@@ -326,7 +327,7 @@ double emu_level_residual(void *h, const double *x, const double *b, double *r)
         double S = 0.0;
         for (int i = 0; i < e->n; ++i)
             if (e->flags[i] < 2) S += x[i];
-        r[e->n] = b[e->n] - (S + x[e->n]);
+        r[e->n] = b[e->n] - (e->mult_row * S + x[e->n]);
         nrm += std::fabs(r[e->n]);
     }
     return nrm;

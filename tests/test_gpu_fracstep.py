@@ -31,7 +31,7 @@ def test_fracstep_3d_grid_ops_match_oracle(host):
     """Predictor, PPE source, push_inhomog_to_rhs and corrector of a 3-D FractionalStepGrid on the device vs the
     oracle's 3-D statements on the operators the host class built (D_x, D_y, D_z, Laplacian: K = 25 stencils of
     a jittered 11^3 cloud, Neumann pressure with implicit elimination)."""
-    pts = host.box_cloud(11, 3, seed=5)
+    pts = host.box_cloud(11, 3, seed=5, edges=False)
     g = host.FracStepGrid.create(pts, polydeg=2, dt=1e-3, mu=0.05, rho=1.0, dim=3, ordering=host.ORDER_MC, tile_points=128)
     o = H.oracle_of_fracstep(g)
     n = g.sizes()["n"]
@@ -90,7 +90,7 @@ def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg):
     The pressure loop is capped at 6 V-cycles per step (both sides reach the cap: 1e-10 is far below what six
     cycles give), so the comparison covers set_uv_bound, predictor, source, push_inhomog_to_rhs, six V-cycles
     with bound_eval_neumann after each, the corrector and fs_residual."""
-    cloud = (lambda n, s: host.square_cloud(n, seed=s)) if dim == 2 else (lambda n, s: host.box_cloud(n, 3, seed=s))
+    cloud = (lambda n, s: host.square_cloud(n, seed=s)) if dim == 2 else (lambda n, s: host.box_cloud(n, 3, seed=s, edges=False))
     clouds = [cloud(n, 12345 + i) for i, n in enumerate(sides)]
     mg = host.FracStepMultigrid(clouds, [deg] * len(sides), dim=dim, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC,
                                 tile_points=128)
@@ -115,3 +115,31 @@ def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg):
             assert H.rel_err(got, want) < 1e-9, step
         assert H.rel_err(g.values()[:n], om.levels[-1].x[:n]) < 1e-9, step
         assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)
+
+
+def test_3d_time_step_converges_to_the_ppe_tolerance(host):
+    """Config-5 shape at test size: a 3-D FractionalStepMultigrid (edge-free box clouds, scaled multiplier row,
+    DESIGN 12) runs the reference's time loop device-resident with the pressure loop iterated to its own tolerance
+    (`while residual >= 1e-10`, FractionalStepSim.cpp:139) -- it gets there (the 3-D Neumann cycle contracts now), in
+    the same number of V-cycles as the oracle loop, with the same fields."""
+    clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate([14, 27])]
+    mg = host.FracStepMultigrid(clouds, [3, 3], dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=0)
+    g = mg.fs_grid()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    g.set_uv_bound()
+    om = H.oracle_of_multigrid(mg)
+    ofs = H.oracle_of_fracstep(g)
+    comps = [ofs.u, ofs.v, ofs.w]
+    for c, vals in zip(comps, _vecs(g)):
+        c[:] = vals
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[c[bpts].copy() for c in comps], coupling=g.coupling(), bcflags=flags)
+    for step in range(2):
+        r_dev, nc_dev = mg.step(max_cycles=400)
+        r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 400)
+        assert nc_dev < 400 and abs(nc_dev - nc_orc) <= 1, (step, nc_dev, nc_orc)     # converged, not capped
+        assert np.isfinite(r_dev) and abs(r_dev - r_orc) <= 1e-6 * abs(r_orc), (step, r_dev, r_orc)
+        for got, want in zip(_vecs(g), comps):
+            assert H.rel_err(got, want) < 1e-6, step

@@ -220,3 +220,39 @@ def test_binary_cloud_container_round_trip(tmp_path):
     ga = host.Grid.create_square(p2, 3, ordering=host.ORDER_NONE)
     gb = host.Grid.create_square(q2, 3, ordering=host.ORDER_NONE)
     assert all(np.array_equal(a, b) for a, b in zip(ga.csr(), gb.csr()))
+
+
+def test_neumann_3d_scaled_multiplier_row_and_edge_free_cloud_converge():
+    """3-D Neumann hierarchies (no reference counterpart).  Two things the 2-D formulation needs in 3-D:
+    the multiplier ROW carries n^(-1/3) instead of 1 (relaxing the bordered system couples the mean of x and the
+    multiplier with strength n/|a_ii| ~ points per side: the constant mode explodes otherwise), and the box cloud has
+    no nodes on its edges and corners (their one-sided n.grad rows are nearly singular).  With both, the CPU oracle's
+    V-cycle contracts on a 10^3 / 19^3 hierarchy; the packed-plan interpreter (the device's arithmetic) follows the
+    oracle through sweeps and residuals with the scaled row."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate([10, 19])]
+    assert len(clouds[1]) == 19 ** 3 - 12 * 17 - 8                 # 12 edges of 17 inner nodes, 8 corners
+    mg = host.Multigrid(clouds, [2, 2], dim=3, neumann=True, ordering=host.ORDER_MC, tile_points=96)
+    la = mg.grid(1).level_arrays()
+    n, rp, col, val = la["n"], la["rowptr"], la["col"], la["val"]
+    row = slice(rp[n], rp[n + 1])
+    offd = val[row][col[row] != n]
+    assert np.all(offd == 1.0 / np.cbrt(float(n))) and val[row][col[row] == n][0] == 1.0
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    assert np.all(val[(col == n) & (rows != n)] == 1.0)            # the column keeps the reference's ones
+    om = H.oracle_of_multigrid(mg)
+    hist = [om.vcycle() for _ in range(14)]
+    assert hist[-1] < 0.25 * hist[0] and hist[-1] < hist[-4], hist
+    lv = H.oracle_level(la)
+    emu = H.EmuLevel(la, tile_ptr=mg.grid(1).tile_ptr(), lanes_per_row=4)
+    rng = np.random.default_rng(3)
+    x0 = rng.standard_normal(len(lv.x))
+    lv.x[:] = x0
+    emu.x[:] = x0
+    lv.sor_sweeps(3)
+    emu.sweeps(3)
+    assert H.rel_err(emu.x, lv.x) < 1e-12
+    r_o, _ = lv.residual(), None
+    r_e, _nrm = emu.residual()
+    assert H.rel_err(r_e, r_o) < 1e-11

@@ -10,7 +10,7 @@ deg = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 host.set_option("device_setup", 1)
 t = time.perf_counter()
-clouds = [host.box_cloud(n, 3, seed=12345 + i) for i, n in enumerate(sides)]
+clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate(sides)]
 mg = host.FracStepMultigrid(clouds, [deg] * len(sides), dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=0)
 g = mg.fs_grid()
 g.prescribe_soln()
@@ -18,6 +18,6 @@ g.set_uv_bound()
 print(f"setup {time.perf_counter() - t:.1f} s, n = {g.sizes()['n']}", flush=True)
 for s in range(steps):
     t = time.perf_counter()
-    r, nc = mg.step(max_cycles=60)
+    r, nc = mg.step(max_cycles=int(sys.argv[4]) if len(sys.argv) > 4 else 200)
     dt = time.perf_counter() - t
     print(f"step {s}: fs_residual {r:.6e}, {nc} V-cycles, {dt * 1e3:.1f} ms ({dt * 1e3 / max(nc, 1):.2f} ms per V-cycle incl. the rest of the step)", flush=True)
