@@ -47,7 +47,11 @@ typedef struct mmg_hierarchy mmg_hierarchy; /* one reference Multigrid         *
 typedef struct mmg_spmv mmg_spmv;           /* generic CSR operator (D_x, ...) */
 
 /* What mmg_level_create needs == the state Grid::sor / residual /
- * bound_eval_neumann / boundaryOp read (grid.h:23-38). */
+ * bound_eval_neumann / boundaryOp read (grid.h:23-38).
+ * With neumann_flag the matrix carries the reference's bordered system (grid.cpp:566-576): column n holds 1 in every
+ * non-Neumann row, row n one entry per non-Neumann point and a_nn = 1.  The row's entries are the reference's ones or
+ * ONE other positive value on all of them (3-D hierarchies scale the row by n^(-1/3)); anything
+ * else is refused (MMG_ERR_UNSUPPORTED). */
 typedef struct {
     int n;                 /* laplaceMatSize_ (points)                          */
     int a_size;            /* laplaceMat_->rows(): n, or n+1 with neumann_flag  */
