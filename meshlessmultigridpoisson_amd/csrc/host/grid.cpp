@@ -75,6 +75,7 @@ Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties pro
     diags = VectorXd((size_t)A_size);
     device_setup_ = default_device_setup;
     point_colouring_ = default_point_colouring;
+    if (default_mult_row > 0.0) multRow_ = default_mult_row;
 }
 
 Grid::~Grid()
@@ -341,6 +342,7 @@ double Grid::multiplier_row_value() const
     return 1.0 / std::cbrt((double)std::max<size_t>(1, points_.size()));
 }
 
+double Grid::default_mult_row = 0.0;
 int Grid::default_device_setup = -1;
 int Grid::default_point_colouring = 1;
 

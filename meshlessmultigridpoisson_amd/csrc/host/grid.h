@@ -60,6 +60,7 @@ public:
     int tile_colours_ = 0;       // mc_order_points: colours to balance over (0 = 10 in 3-D, 5 in 2-D)
     double multRow_ = -1.0;      // off-diagonal value of the Neumann multiplier row; <= 0: 1 in 2-D, n^(-1/3) in 3-D
     double multiplier_row_value() const;
+    static double default_mult_row;  // value new grids start with (mmgh_set_option "multiplier_row_ppm", millionths; 0 = automatic)
     int geom_version_ = 0;       // bumped by apply_order: caches keyed on the point order compare it
     int point_colouring_ = 1;    // mc_order_points, points of a tile: 0 greedy in tile order, 1 smallest-last + iterated greedy
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring")
