@@ -53,7 +53,7 @@ def main():
     wall = time.perf_counter() - t0
     out = {"workload": f"{a.dim}-D {sides[-1]}^{a.dim} = {sides[-1] ** a.dim} points, {a.levels} levels {sides}, polyDeg {polys}, omega {a.omega}, iters {a.iters}",
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
-           "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]],
+           "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]], "residual_before_last_cycle": float(res[-1]),
            "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
     if a.per_level:
         import numpy as np
