@@ -238,6 +238,20 @@ class Grid:
         lib().mmgh_grid_sizes(self.h, out.ctypes.data_as(_ip))
         return dict(zip(["n", "a_size", "nnz", "neumann", "nb", "nbpts", "n_tiles", "stencil"], out.tolist()))
 
+    def relaxation(self):
+        """(omega, iters) of this grid's GridProperties."""
+        w, it = C.c_double(0), C.c_int(0)
+        f = lib().mmgh_grid_get_relaxation
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        f(self.h, C.byref(w), C.byref(it))
+        return w.value, it.value
+
+    def set_relaxation(self, omega, iters):
+        """GridProperties::omega / iters of this grid alone (e.g. a coarse grid relaxed longer than the fine ones)."""
+        f = lib().mmgh_grid_set_relaxation
+        f.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        f(self.h, float(omega), int(iters))
+
     def csr(self):
         s = self.sizes()
         rowptr = np.zeros(s["a_size"] + 1, dtype=np.int32)

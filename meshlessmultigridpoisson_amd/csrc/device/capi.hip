@@ -211,6 +211,7 @@ struct PlanGpu {
         dev.phase_tiles = phase_tiles.p;
         dev.L = P.L;
         dev.dense = P.dense ? 1 : 0;
+        dev.dense_long = P.dense_long ? 1 : 0;
         dev.waves = P.waves;
         max_levels = 0;
         for (const TileDesc &t : P.tiles) max_levels = std::max(max_levels, (int)t.n_levels);

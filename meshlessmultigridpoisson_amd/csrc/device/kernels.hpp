@@ -14,6 +14,7 @@ struct PlanDev {
     const int32_t *phase_tiles = nullptr;
     int L = 4;
     int dense = 0;       // Plan::dense: fixed-shape groups, `waves` wavefronts per tile (kernels_mw.hip)
+    int dense_long = 0;  // Plan::dense_long: rows may span several row slots of a group
     int waves = 1;
     int slot_bits = 16;  // Plan::slot_bits
     int n_tiles = 0;

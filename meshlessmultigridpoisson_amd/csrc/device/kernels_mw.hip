@@ -93,7 +93,7 @@ __device__ __forceinline__ unsigned dense_slot(const DenseRegs<P> &g, int q)
 }
 
 // LDS: xs[n_slots] | bs[n_own] | red[NW] (cross-wavefront partial sums)
-template <int L, int MODE, int P, bool SC1, int NW, int DEPTH>
+template <int L, int MODE, int P, bool SC1, int NW, int DEPTH, bool LONG = false>
 __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int tile, unsigned char *smem, const double lam)
 {
     using S = DenseShape<L, P>;
@@ -185,8 +185,24 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
             acc1 = fma(g.v[h].y, xv[2 * h + 1], acc1);
         }
         if (P & 1) acc0 = fma(g.vlast, xv[P - 1], acc0);
-        const double acc = row_sum<L>(acc0 + acc1);
+        double acc = row_sum<L>(acc0 + acc1);
         const uint32_t gid = g.info.x;
+        if (LONG) {
+            // Plan::dense_long: a row may continue in the row slots after its own (gid == kNoRow, self == kContSlot);
+            // the head slot adds their sums, nearest first.  L = 16: four slots per wavefront.
+            constexpr int G = 64 / L;
+            const int slot = lane / L;
+            const int cont = (gid == kNoRow && (g.info.y & 0xffffu) == kContSlot) ? 1 : 0;
+            const double u1 = __shfl_down(acc, L, 64), u2 = __shfl_down(acc, 2 * L, 64), u3 = __shfl_down(acc, 3 * L, 64);
+            const int m1 = __shfl_down(cont, L, 64), m2 = __shfl_down(cont, 2 * L, 64), m3 = __shfl_down(cont, 3 * L, 64);
+            if (slot + 1 < G && m1) {
+                acc += u1;
+                if (slot + 2 < G && m2) {
+                    acc += u2;
+                    if (slot + 3 < G && m3) acc += u3;
+                }
+            }
+        }
         if (sub == 0 && gid != kNoRow) {
             const uint32_t self = g.info.y & 0xffffu, flags = g.info.y >> 16;
             const double invd = __longlong_as_double(((unsigned long long)g.info.w << 32) | g.info.z);
@@ -291,7 +307,7 @@ template <int P>
 constexpr int kDepthMw = P <= 4 ? 4 : 3;
 
 // one launch per phase: one workgroup of NW wavefronts per tile
-template <int L, int MODE, int P, int NW>
+template <int L, int MODE, int P, int NW, bool LONG = false>
 __global__ __launch_bounds__(64 * NW) void tile_kernel_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel_mw(TileArgs a)
     const int tile = a.tile_list ? a.tile_list[idx] : idx;
     double lam = 0.0;
     if (a.lambda) lam = *a.lambda;
-    process_tile_mw<L, MODE, P, false, NW, kDepthMw<P>>(a, tile, smem, lam);
+    process_tile_mw<L, MODE, P, false, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
 }
 
 // Workgroup-wide broadcast of a value that wavefront 0 holds (the same in all its lanes).
@@ -324,7 +340,7 @@ __device__ __forceinline__ unsigned wg_bcast(unsigned v, bool wave0, unsigned *s
 
 // all tiles of a tiny level resident at once (grid <= resident workgroups): workgroup b owns tile b for every
 // phase and every fused sweep of the launch; protocol of sweep_resident_kernel (kernels.hip)
-template <int L, int P, int NW>
+template <int L, int P, int NW, bool LONG = false>
 __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<2>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have; LDS free for the next sweep
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
 
 // dependency-driven single launch: resident workgroups draw tiles from the ticket counter in phase order;
 // protocol of sweep_persistent_kernel (kernels.hip)
-template <int L, int P, int NW>
+template <int L, int P, int NW, bool LONG = false>
 __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<8>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
 
 enum MwKernel { MW_TILE_SOR, MW_TILE_RESID, MW_RESIDENT, MW_PERSISTENT };
 
-template <int L, int P, int NW>
+template <int L, int P, int NW, bool LONG = false>
 hipError_t launch_mw_LPN(MwKernel k, const TileArgs &a, int workers, hipStream_t s, int *occ)
 {
     const size_t lds = a.p.lds_bytes;
@@ -390,20 +406,20 @@ hipError_t launch_mw_LPN(MwKernel k, const TileArgs &a, int workers, hipStream_t
     switch (k) {
     case MW_TILE_SOR: {
         const int per = (a.n_list + 7) / 8;
-        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_SOR, P, NW>), dim3((unsigned)(per * 8)), block, lds, s, a);
+        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_SOR, P, NW, LONG>), dim3((unsigned)(per * 8)), block, lds, s, a);
         break;
     }
     case MW_TILE_RESID: {
         const int per = (a.n_list + 7) / 8;
-        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_RESID, P, NW>), dim3((unsigned)(per * 8)), block, lds, s, a);
+        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_RESID, P, NW, LONG>), dim3((unsigned)(per * 8)), block, lds, s, a);
         break;
     }
     case MW_RESIDENT:
-        hipLaunchKernelGGL((sweep_resident_mw<L, P, NW>), dim3((unsigned)a.n_list), block, lds, s, a);
+        hipLaunchKernelGGL((sweep_resident_mw<L, P, NW, LONG>), dim3((unsigned)a.n_list), block, lds, s, a);
         break;
     case MW_PERSISTENT:
-        if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, sweep_persistent_mw<L, P, NW>, 64 * NW, lds);
-        hipLaunchKernelGGL((sweep_persistent_mw<L, P, NW>), dim3((unsigned)workers), block, lds, s, a);
+        if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, sweep_persistent_mw<L, P, NW, LONG>, 64 * NW, lds);
+        hipLaunchKernelGGL((sweep_persistent_mw<L, P, NW, LONG>), dim3((unsigned)workers), block, lds, s, a);
         break;
     }
     return hipGetLastError();
@@ -443,6 +459,12 @@ hipError_t launch_mw_L(MwKernel k, const TileArgs &a, int workers, hipStream_t s
 hipError_t launch_mw(MwKernel k, const TileArgs &a, int workers, hipStream_t s, int *occ = nullptr)
 {
     if (!a.p.dense) return hipErrorInvalidValue;
+    if (a.p.dense_long) {  // multi-slot rows: 16 lanes x 4 entries, 4 or 6 wavefronts per tile
+        if (a.p.L != 16 || a.p.max_plen != 4) return hipErrorInvalidValue;
+        if (a.p.waves == 4) return launch_mw_LPN<16, 4, 4, true>(k, a, workers, s, occ);
+        if (a.p.waves == 6) return launch_mw_LPN<16, 4, 6, true>(k, a, workers, s, occ);
+        return hipErrorInvalidValue;
+    }
     switch (a.p.L) {
     case 8: return launch_mw_L<8>(k, a, workers, s, occ);
     case 16: return launch_mw_L<16>(k, a, workers, s, occ);

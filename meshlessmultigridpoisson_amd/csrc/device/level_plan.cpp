@@ -53,11 +53,16 @@ int dense_lanes(int lanes_per_row, double avg_row_len)
     return avg_row_len >= 44.0 ? 16 : 8;
 }
 
-std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits, int waves)
+std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits, int waves, bool dense_long)
 {
-    if (waves > 1 && !exact) {  // dense layout first; rows too long for it -> the packed layout below
+    if (waves > 1 && !exact) {  // dense layout first; rows too long for it -> rows over several row slots -> packed layout
         const int Ld = dense_lanes(d.lanes_per_row, (double)d.rowptr[d.n] / std::max(1, d.n));
-        const std::string derr = build_level_plan(d, Ld, out, false, 16, -waves);
+        std::string derr = build_level_plan(d, Ld, out, false, 16, -waves);
+        if (derr.rfind("rows-too-long-for-dense", 0) == 0) {
+            // (the implicitly eliminated Neumann levels of 3-D hierarchies: up to ~200 entries per row)
+            const int wl = waves >= 6 ? 6 : 4;  // wavefront counts the long-row kernels exist for
+            derr = build_level_plan(d, 16, out, false, 16, -wl, true);
+        }
         if (derr.rfind("rows-too-long-for-dense", 0) != 0) return derr;
         waves = 1;
     }
@@ -113,6 +118,7 @@ std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exa
         s.tile_phase_hint = (attempt == 0 && d.tile_ptr && d.n_tiles > 0) ? d.tile_phase : nullptr;
         s.slot_bits = (slot_bits == 12 && !exact && !dense_waves && (L == 2 || L == 4 || L == 8 || L == 16)) ? 12 : 16;
         s.dense_waves = dense_waves;
+        s.dense_long = dense_long && dense_waves > 0;
         err = build_plan(s, out);
         if (err.rfind("slots-exceed-12-bit", 0) == 0) {  // a tile stages more than 4096 values: 16-bit slots
             s.slot_bits = 16;

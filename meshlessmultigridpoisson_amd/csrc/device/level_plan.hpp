@@ -22,7 +22,7 @@ std::string build_gather_plan_host(const CsrView &A, const std::vector<int32_t> 
 // dense_lanes(L, average row length) lanes per row; falls back to the packed layout (waves 1) when the
 // rows are too long for it.
 std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact = false, int slot_bits = 16,
-                             int waves = 1);
+                             int waves = 1, bool dense_long = false);
 // lanes per row of a dense level plan: the caller's choice if it is 4, 8 or 16, else 16 for long rows
 // (3-D K = 50: 4 entries per lane), 8 for short ones
 int dense_lanes(int lanes_per_row, double avg_row_len);

@@ -236,6 +236,76 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         // sequential order (strictly later round), rows of one round are mutually uncoupled.
         const int NW = s.dense_waves, P = s.dense_plen;
         const int cap = NW * G;
+        if (s.dense_long) {
+            // Rows of up to G * P * L entries: a row takes ceil(len / (P * L)) CONSECUTIVE row slots of one group (the
+            // kernel adds the slot sums of a row; continuation slots carry gid = kNoRow, self = kContSlot).  Rounds by
+            // list scheduling as below, a row going to the group of its round with the most free slots.
+            const int per_slot = P * L;
+            std::vector<int32_t> need(m), round_of(m, 0), group_of(m, 0), slot_of_row(m, 0);
+            std::vector<std::vector<int>> freeg;  // per round: free slots of each of the NW groups
+            for (int k = 0; k < m; ++k) {
+                need[k] = std::max(1, (int)((ent(k).size() + (size_t)per_slot - 1) / (size_t)per_slot));
+                if (need[k] > G) { tb.err = "rows-too-long-for-dense"; return; }
+                int r = 0;
+                if (s.in_place)
+                    for (int32_t j : lower(k)) r = std::max(r, round_of[j] + 1);
+                else
+                    r = freeg.empty() ? 0 : (int)freeg.size() - 1;
+                for (;; ++r) {
+                    if (r >= (int)freeg.size()) freeg.resize((size_t)r + 1, std::vector<int>((size_t)NW, G));
+                    int best = -1;
+                    for (int w = 0; w < NW; ++w)
+                        if (freeg[(size_t)r][(size_t)w] >= need[k] && (best < 0 || freeg[(size_t)r][(size_t)w] > freeg[(size_t)r][(size_t)best])) best = w;
+                    if (best >= 0) {
+                        round_of[k] = r;
+                        group_of[k] = best;
+                        slot_of_row[k] = G - freeg[(size_t)r][(size_t)best];
+                        freeg[(size_t)r][(size_t)best] -= need[k];
+                        break;
+                    }
+                }
+            }
+            const int n_rounds = (int)freeg.size();
+            const size_t GB = dense_group_bytes(L, P);
+            tb.blob.assign((size_t)n_rounds * NW * GB, 0);
+            uint8_t *B = tb.blob.data();
+            std::vector<uint32_t> heads((size_t)n_rounds * NW, 0);
+            for (int g = 0; g < n_rounds * NW; ++g) {  // everything empty first: no row, value 0, zero slot
+                uint8_t *gp = B + (size_t)g * GB;
+                for (int i = 0; i < G; ++i) {
+                    RowInfo ri{RowMeta{kNoRow, kNoSlot, 0}, 1.0};
+                    std::memcpy(gp + (size_t)16 * i, &ri, 16);
+                    const double one = 1.0;
+                    std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &one, 8);
+                }
+                for (int lane = 0; lane < 64; ++lane)
+                    for (size_t q = 0; q < dense_slot_bytes(P) / 2; ++q)
+                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_slot, 2);
+            }
+            for (int k = 0; k < m; ++k) {
+                const int g = round_of[k] * NW + group_of[k];
+                uint8_t *gp = B + (size_t)g * GB;
+                const int i0 = slot_of_row[k];
+                RowInfo ri{meta[k], 1.0 / diag[k]};
+                if (!s.extract_diag) ri.inv_diag = 1.0;
+                std::memcpy(gp + (size_t)16 * i0, &ri, 16);
+                std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i0, &diag[k], 8);
+                for (int j = 1; j < need[k]; ++j) {
+                    RowInfo rc{RowMeta{kNoRow, kContSlot, 0}, 1.0};
+                    std::memcpy(gp + (size_t)16 * (i0 + j), &rc, 16);
+                }
+                const auto e = ent(k);
+                for (size_t x = 0; x < e.size(); ++x) {
+                    const int j = (int)(x / (size_t)per_slot), y = (int)(x % (size_t)per_slot);
+                    const int q = y / L, lane = (i0 + j) * L + y % L;
+                    std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
+                    std::memcpy(gp + dense_slot_off(L, P, q, lane), &e[x].slot, 2);
+                }
+                heads[(size_t)g]++;
+            }
+            for (uint32_t h : heads) tb.ghead.push_back(h | ((uint32_t)P << 8));
+            return;
+        }
         std::vector<int32_t> round_of(m, 0), fill;
         for (int k = 0; k < m; ++k) {
             int r = 0;
@@ -381,8 +451,14 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         // entries per lane: the diagonal (and the multiplier column) leave the row, everything else may stay
         const int drop = (s.extract_diag ? 1 : 0) + (s.mult_col >= 0 ? 1 : 0);
         const int need = (std::max(1, maxlen - drop) + L - 1) / L;
-        sd.dense_plen = dense_plen_class(need);
-        if (!sd.dense_plen) return "rows-too-long-for-dense";
+        if (s.dense_long) {  // 16 lanes x 4 entries per row slot, a row takes up to the 4 slots of a group
+            if (L != 16) return "dense layout with long rows needs 16 lanes per row";
+            sd.dense_plen = 4;
+            if (need > 4 * (64 / L)) return "rows-too-long-for-dense";
+        } else {
+            sd.dense_plen = dense_plen_class(need);
+            if (!sd.dense_plen) return "rows-too-long-for-dense";
+        }
     }
 
     Ctx c;
@@ -438,6 +514,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     P.dense = s.dense_waves > 0;
     P.waves = s.dense_waves > 0 ? s.dense_waves : 1;
     P.dense_plen = sd.dense_plen;
+    P.dense_long = s.dense_waves > 0 && s.dense_long;
     P.slot_bits = s.slot_bits == 12 ? 12 : 16;
     P.n_tiles = s.n_tiles;
     P.tiles.resize(s.n_tiles);

@@ -125,6 +125,8 @@ static_assert(sizeof(RowInfo) == 16, "RowInfo layout");
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;  // RowMeta::gid of an empty row slot (dense plans)
 constexpr uint16_t kNoSlot = 0xFFFF;
+constexpr uint16_t kContSlot = 0xFFFE;   // RowMeta::self of a row slot that CONTINUES the row of the slot before it
+                                         // (gid == kNoRow; dense plans with long rows, Plan::dense_long)
 constexpr int kMaxSlots = 7680;  // (slots + own rhs) * 8 B + group heads must fit 64 KiB of LDS
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -173,6 +175,8 @@ struct Plan {
     bool dense = false;                // dense multi-wavefront layout (see the header comment)
     int waves = 1;                     // wavefronts per tile (dense plans: groups per round)
     int dense_plen = 0;                // entries per lane of every group (dense plans: one of kDensePlens)
+    bool dense_long = false;           // a row may span several consecutive row slots of its group (kContSlot): the rows
+                                       // of an implicitly eliminated Neumann level in 3-D hold up to ~200 entries
     int slot_bits = 16;                // 16, or 12 when every tile has <= 4096 LDS slots (level plans, L = 2/4)
     int n_tiles = 0;
     std::vector<TileDesc> tiles;
@@ -235,6 +239,8 @@ struct PlanSpec {
     // stored entries; 16-bit slots); fails with "rows-too-long-for-dense" otherwise
     int dense_waves = 0;
     int dense_plen = 0;         // set by build_plan
+    bool dense_long = false;    // rows longer than dense_plen * L entries take several row slots (16 lanes per row,
+                                // 4 entries per lane, at most 4 slots = 256 entries) instead of failing
 };
 
 // Returns empty string on success, otherwise the reason (plan left unusable).

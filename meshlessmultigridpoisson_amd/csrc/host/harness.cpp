@@ -256,6 +256,20 @@ void mmgh_grid_sizes(void *gp, int *out)  // n, a_size, nnz, neumann, n_boundari
     out[6] = g->tile_ptr_.empty() ? 0 : (int)g->tile_ptr_.size() - 1;
     out[7] = g->properties_.stencilSize;
 }
+// GridProperties::omega / iters of ONE grid (the reference keeps them per grid, gridclasses.hpp:6-14): a hierarchy may
+// relax its coarse grids longer than its fine ones
+void mmgh_grid_get_relaxation(void *gp, double *omega, int *iters)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    *omega = g->properties_.omega;
+    *iters = g->properties_.iters;
+}
+void mmgh_grid_set_relaxation(void *gp, double omega, int iters)
+{
+    Grid *g = static_cast<Grid *>(gp);
+    g->properties_.omega = omega;
+    g->properties_.iters = iters;
+}
 void mmgh_grid_get_csr(void *gp, int *rowptr, int *col, double *val)
 {
     Grid *g = static_cast<Grid *>(gp);

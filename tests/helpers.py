@@ -86,7 +86,9 @@ def oracle_of_multigrid(mg):
     nl = mg.nlevels
     levels = []
     for l in range(nl):
-        la = mg.grid(l).level_arrays(mg.omega, mg.iters)
+        g = mg.grid(l)
+        w, it = g.relaxation() if hasattr(g, "relaxation") else (mg.omega, mg.iters)   # per grid (gridclasses.hpp:6-14)
+        la = g.level_arrays(w, it)
         levels.append(oc.Level(la["n"], la["rowptr"], la["col"], la["val"], la["x0"], la["b0"], la["bcflags"],
                                la["neumann"], la["omega"], la["iters"], la["btype"], la["bptr"], la["bpts"],
                                la["bvals"]))
@@ -159,6 +161,7 @@ def emu_lib():
         L.emu_level_owned_sum.restype = C.c_double
         L.emu_level_slot_bits.argtypes = [C.c_void_p]
         L.emu_level_waves.argtypes = [C.c_void_p]
+        L.emu_level_dense_long.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.argtypes = [C.c_void_p]
         L.emu_level_stream_bytes.restype = C.c_longlong
         L.emu_level_nnz.argtypes = [C.c_void_p]
@@ -192,6 +195,12 @@ class EmuLevel:
         out = np.zeros(6, dtype=np.int32)
         self.L.emu_level_info(self.h, out.ctypes.data_as(_ip))
         return dict(zip(["n_tiles", "n_phases", "n_groups", "max_slots", "b_tiles", "b_phases"], out.tolist()))
+
+    def waves(self):
+        return int(self.L.emu_level_waves(self.h))
+
+    def dense_long(self):
+        return bool(self.L.emu_level_dense_long(self.h))
 
     def sweeps(self, k):
         self.L.emu_level_sweeps(self.h, self.x.ctypes.data_as(_dp), self.b.ctypes.data_as(_dp), self.omega, int(k))

@@ -49,13 +49,11 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
             const uint8_t *gp = base + (size_t)(r0 + w) * GB;
             const uint32_t h = P.ghead[td.ghead_off + r0 + w];
             int seen = 0;
+            // sum of every row slot first (a long row continues in the slots after its own: kContSlot)
+            double slot_sum[64];
+            RowInfo infos[64];
             for (int i = 0; i < G; ++i) {
-                RowInfo ri;
-                std::memcpy(&ri, gp + (size_t)16 * i, 16);
-                if (ri.meta.gid == kNoRow) continue;
-                ++seen;
-                double d;
-                std::memcpy(&d, gp + off_diag + (size_t)8 * i, 8);
+                std::memcpy(&infos[i], gp + (size_t)16 * i, 16);
                 double lane_acc[64] = {0};
                 for (int sub = 0; sub < L; ++sub) {
                     const size_t lane = (size_t)i * L + sub;
@@ -72,7 +70,20 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
                 }
                 for (int m = 1; m < L; m <<= 1)
                     for (int sub = 0; sub < L; sub += 2 * m) lane_acc[sub] += lane_acc[sub + m];
-                upd.push_back(Upd{ri.meta, lane_acc[0], d, ri.inv_diag});
+                slot_sum[i] = lane_acc[0];
+            }
+            for (int i = 0; i < G; ++i) {
+                const RowInfo &ri = infos[i];
+                if (ri.meta.gid == kNoRow) {
+                    if (ri.meta.self == kContSlot && !P.dense_long) g_err = "continuation slot in a plan without long rows";
+                    continue;
+                }
+                ++seen;
+                double d;
+                std::memcpy(&d, gp + off_diag + (size_t)8 * i, 8);
+                double acc = slot_sum[i];
+                for (int j = i + 1; j < G && infos[j].meta.gid == kNoRow && infos[j].meta.self == kContSlot; ++j) acc += slot_sum[j];
+                upd.push_back(Upd{ri.meta, acc, d, ri.inv_diag});
             }
             if (seen != (int)(h & 0xffu)) g_err = "dense group head disagrees with its row slots";
         }
@@ -247,6 +258,7 @@ void emu_level_info(void *h, int *out6)
 
 int emu_level_slot_bits(void *h) { return static_cast<Emu *>(h)->A.slot_bits; }
 int emu_level_waves(void *h) { return static_cast<Emu *>(h)->A.dense ? static_cast<Emu *>(h)->A.waves : 0; }
+int emu_level_dense_long(void *h) { return static_cast<Emu *>(h)->A.dense_long ? 1 : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
 

@@ -57,11 +57,20 @@ def test_dense_multiwave_layout_matches_oracle(name, tile, L, waves):
 
 
 def test_dense_layout_falls_back_for_long_rows():
-    """Rows of more than 8 entries per lane (here 150 entries: 10 per lane at 16 lanes) do not fit any dense group
-    shape: the level keeps the packed stream, results unchanged.  A request for 4 lanes per row is served with the
-    dense layout's own choice (8 or 16 lanes)."""
+    """Rows of more than 8 entries per lane do not fit one dense row slot: up to 256 entries they take several row slots
+    (Plan::dense_long, 150 entries here: three slots of 16 lanes x 4 entries); beyond that (270 entries) the level keeps
+    the packed stream.  Results unchanged either way.  A request for 4 lanes per row is served with the dense layout's
+    own choice (8 or 16 lanes)."""
     rng = np.random.default_rng(2)
-    n, k = 220, 150
+    for n, k, want_waves in ((220, 150, 4), (300, 270, 0)):
+        _long_rows_case(rng, n, k, want_waves)
+    lib = H.emu_lib()
+    case = H.load_case("dirichlet_3level")
+    e4 = H.EmuLevel(H.level_arrays(case, 2), tile_size=64, lanes_per_row=4, waves_per_tile=4)   # K = 37
+    assert lib.emu_level_waves(e4.h) == 4
+
+
+def _long_rows_case(rng, n, k, want_waves):
     rowptr, col, val = [0], [], []
     for i in range(n):
         c = np.sort(rng.choice(np.delete(np.arange(n), i), size=k - 1, replace=False))
@@ -76,15 +85,11 @@ def test_dense_layout_falls_back_for_long_rows():
               bptr=np.zeros(1, dtype=np.int32), bpts=np.zeros(0, dtype=np.int32), bvals=np.zeros(0),
               x0=np.zeros(n), b0=rng.standard_normal(n))
     e = H.EmuLevel(la, tile_size=64, lanes_per_row=16, waves_per_tile=4)
-    lib = H.emu_lib()
-    assert lib.emu_level_waves(e.h) == 0
+    assert e.waves() == want_waves and e.dense_long() == (want_waves > 0)
     o = H.oracle_level(la)
     o.sor_sweeps(2)
     e.sweeps(2)
     assert H.rel_err(e.x, o.x) < 1e-12
-    case = H.load_case("dirichlet_3level")
-    e4 = H.EmuLevel(H.level_arrays(case, 2), tile_size=64, lanes_per_row=4, waves_per_tile=4)   # K = 37
-    assert lib.emu_level_waves(e4.h) == 4
 
 
 @pytest.mark.parametrize("name", ["neumann_2level", "neumann_3level"])
@@ -205,3 +210,31 @@ def test_threaded_csc_to_csr_keeps_eigens_accumulation_order():
         seq[i] = s
     assert np.array_equal(y, seq)
     assert np.allclose(y, want, rtol=1e-12, atol=1e-12)
+
+
+def test_dense_groups_with_rows_over_several_row_slots():
+    """Plan::dense_long: the implicitly eliminated Neumann level of a 3-D hierarchy has rows of up to ~200 entries, more
+    than the 128 a dense row slot of 16 lanes holds at most.  Such rows take several consecutive row slots of one group
+    (continuation slots: gid = kNoRow, self = kContSlot), the head slot adds their sums.  The adversarial interpreter of
+    the packed bytes follows the oracle through sweeps and residual, with 4 and with 6 wavefronts per tile."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    pts = host.box_cloud(15, 3, seed=11, edges=False)
+    g = host.Multigrid([pts], [3], dim=3, neumann=True, ordering=host.ORDER_MC, tile_points=128).grid(0)
+    la = g.level_arrays()
+    n = la["n"]
+    rowlen = np.diff(la["rowptr"])[:n]
+    assert rowlen.max() > 130, rowlen.max()                      # longer than any single dense row slot
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal(len(la["x0"]))
+    for waves in (4, 6):
+        lv = H.oracle_level(la)
+        emu = H.EmuLevel(la, tile_ptr=g.tile_ptr(), waves_per_tile=waves)
+        assert emu.waves() == waves and emu.dense_long()
+        lv.x[:] = x0
+        emu.x[:] = x0
+        lv.sor_sweeps(3)
+        emu.sweeps(3)
+        assert H.rel_err(emu.x, lv.x) < 1e-12, waves
+        r_e, _nrm = emu.residual()
+        assert H.rel_err(r_e, lv.residual()) < 1e-11, waves
