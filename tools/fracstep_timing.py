@@ -12,6 +12,8 @@ host.set_option("device_setup", 1)
 t = time.perf_counter()
 clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate(sides)]
 mg = host.FracStepMultigrid(clouds, [deg] * len(sides), dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=0)
+if len(sys.argv) > 5:
+    mg.grid(0).set_relaxation(1.4, int(sys.argv[5]))   # sweeps on the coarse grid (GridProperties::iters of that grid)
 g = mg.fs_grid()
 g.prescribe_soln()
 g.set_uv_bound()
