@@ -40,6 +40,11 @@
 //     followed by double val_last[64] | uint16 slot[64][plen], padded to dense_slot_bytes(plen) per lane
 //     (8, 12 or 16 B: one load).  dense_val_off() / dense_slot_off() below are THE definition.
 //     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
+//   * Plan::dense_long (16 lanes per row, 4 entries per lane): a row of more than 64 entries takes up to four
+//     CONSECUTIVE row slots of one group; its entries fill them in order, the continuation slots carry
+//     gid = 0xFFFFFFFF and self = kContSlot, the kernel adds their sums to the head slot's (nearest first).  A row
+//     goes to the group of its round that has the most free slots.  (Neumann levels of 3-D hierarchies: the
+//     implicit elimination leaves rows of up to ~200 entries.)
 #pragma once
 #include <chrono>
 #include <memory>
