@@ -78,6 +78,7 @@ def parse():
                     help="N>1: weak = --nside^dim points per rank; strong = one --total-nside^dim cloud shared by all ranks")
     ap.add_argument("--total-nside", type=int, default=342, help="--scaling strong: points per axis of the whole cloud")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the two whole-V-cycle legs (N=1)")
+    ap.add_argument("--no-fracstep", action="store_true", help="skip the 3-D fractional-step leg (N=1)")
     ap.add_argument("--vcycle-cycles", type=int, default=10)
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
@@ -207,6 +208,38 @@ def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
         rd = [mg.vcycle() for _ in range(oracle_cycles)]
         out["max_rel_residual_diff_vs_cpu_oracle"] = float(max(abs(x - y) / y for x, y in zip(rd, ro)))
     return out
+
+
+def fracstep_leg(steps=2, coarse_iters=60):
+    """BASELINE configs[4]'s per-GPU share on ONE GPU: the reference's fractional-step time loop
+    (FractionalStepSim.cpp:130-156: predictor, PPE source, `while residual >= 1e-10: vCycle; bound_eval_neumann`,
+    corrector) device-resident on a 54^3 / 108^3 FractionalStepMultigrid (1.26e6 points = 1e7 / 8), 3-D extension of
+    DESIGN section 12 (edge-free clouds, scaled multiplier row); GridProperties::iters of the coarse grid alone is
+    raised so that the pressure loop converges in O(150) cycles."""
+    from meshlessmultigridpoisson_amd import _host
+    t0 = time.perf_counter()
+    sides = [54, 108]
+    clouds = [_host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate(sides)]
+    mg = _host.FracStepMultigrid(clouds, [3, 3], dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=_host.ORDER_MC, tile_points=0)
+    mg.grid(0).set_relaxation(1.4, coarse_iters)
+    g = mg.fs_grid()
+    g.prescribe_soln()
+    g.set_uv_bound()
+    t_setup = time.perf_counter() - t0
+    mg.step(max_cycles=3)   # warm-up: device hierarchy, operators
+    recs = []
+    for _ in range(steps):
+        t = time.perf_counter()
+        r, nc = mg.step(max_cycles=600)
+        recs.append((time.perf_counter() - t, nc, r))
+    sec = float(np.median([x[0] for x in recs]))
+    cyc = int(np.median([x[1] for x in recs]))
+    return {"workload": "3-D fractional step (FractionalStepSim.cpp:130-156), 54^3 / 108^3 FractionalStepMultigrid, "
+                        f"{g.sizes()['n']} points (BASELINE configs[4]: 1e7 points over 8 GPUs = this per GPU), RBF-FD degree 3 "
+                        f"(K=50), dt 1e-3, pressure loop to 1e-10, {coarse_iters} sweeps on the coarse grid, 5 on the fine one",
+            "points": g.sizes()["n"], "time_steps": steps, "seconds_per_time_step": sec, "vcycles_per_time_step": cyc,
+            "ms_per_vcycle_incl_rest_of_step": sec / max(cyc, 1) * 1e3, "pressure_loop_converged": bool(cyc < 600),
+            "fs_residual": float(recs[-1][2]), "setup_seconds": round(t_setup, 1)}
 
 
 def spawn_ranks(a):
@@ -508,6 +541,11 @@ def main():
         out["spmv"] = spmv
         if vcycles:
             out["vcycle"] = vcycles
+        if not dd and not a.no_fracstep and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:
+            try:
+                out["fracstep"] = fracstep_leg()
+            except Exception as e:  # noqa: BLE001 -- the sweep figures do not depend on this leg
+                out["fracstep"] = {"workload": "3-D fractional step", "error": str(e)}
         if verify is not None:
             out["config"]["persistent_vs_phase_launches"] = verify
         if not a.no_cpu and world == 1:
