@@ -13,7 +13,8 @@ out=$root/gpurun_out
 export TMPDIR=/tmp
 # (the run includes the two whole-V-cycle legs: the kernel statistics then also show the dense multi-wavefront
 #  kernels of the small levels, the residual and the transfer kernels)
-cmd="$root/bench.py --steps 16 --warmup 16 --no-cpu"
+# (without the fractional-step leg: its ~1e5 small launches would make the kernel trace too large to bring back)
+cmd="$root/bench.py --steps 16 --warmup 16 --no-cpu --no-fracstep"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_stats -- python3 $cmd > $out/${tag}_profiled_run_bench.json 2> $out/${tag}_stats.log
 echo "stats pass done"
@@ -25,3 +26,5 @@ cd $root
 python3 profiles/summarize.py $tag $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write $out/${tag}_profiled_run_bench.json
 cp $out/${tag}_profiled_run_bench.json profiles/ 2>/dev/null || true
 mkdir -p $out/profiles_$tag && cp profiles/${tag}_* profiles/pmc_traffic.json $out/profiles_$tag/
+# the raw traces stay on the box: gpurun brings back at most 64 MiB
+rm -rf $out/${tag}_stats $out/${tag}_fetch $out/${tag}_write
