@@ -298,3 +298,36 @@ def test_neumann_3d_hierarchy_follows_oracle_and_converges(host):
         assert np.array_equal(me.grid(1).values(), oe.levels[1].x)
     finally:
         _capi.set_option("exact_arithmetic", 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 4], ids=["per-phase", "auto", "single-launch"])
+def test_long_row_dense_groups_match_oracle_in_every_launch_mode(host, mode):
+    """Plan::dense_long on the device: a 3-D Neumann level (rows of up to ~200 entries over several row slots) through
+    the per-phase launches, the automatic choice and the dependency-driven single launch -- sweeps, Neumann boundary
+    solve, multiplier update and residual against the CPU oracle."""
+    from meshlessmultigridpoisson_amd import _capi
+    pts = host.box_cloud(17, 3, seed=21, edges=False)
+    mg = host.Multigrid([pts], [3], dim=3, neumann=True, ordering=host.ORDER_MC, tile_points=0)
+    g = mg.grid(0)
+    la = g.level_arrays()
+    assert np.diff(la["rowptr"])[:la["n"]].max() > 130
+    lvo = H.oracle_level(la)
+    sz = g.sizes()
+    rng = np.random.default_rng(9)
+    x0 = rng.standard_normal(sz["a_size"])
+    _capi.set_option("persistent_sweep", mode)
+    try:
+        g.set_values(x0)
+        lvo.x[:] = x0
+        lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
+        info = lv.info()
+        assert info["waves_per_tile"] in (4, 6) and info["lanes_per_row"] == 16
+        for _ in range(3):
+            g.sor()
+            lvo.sor()
+        assert H.rel_err(g.values(), lvo.x) < 1e-12
+        r = lv.residual_vector() if hasattr(lv, "residual_vector") else None
+        if r is not None:
+            assert H.rel_err(r, lvo.residual()) < 1e-11
+    finally:
+        _capi.set_option("persistent_sweep", 1)
