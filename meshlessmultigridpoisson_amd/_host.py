@@ -480,6 +480,22 @@ class Multigrid:
             _lib.mmgh_mg_destroy(self.h)
             self.h = None
 
+    @classmethod
+    def annulus(cls, clouds, polydegs, k=1, ordering=ORDER_MC, tile_points=0, omega=1.4, iters=5):
+        """The reference's "concentric_circles" test problem (testing_functions.cpp:107-135): annulus 0.25 <= r <= 0.5
+        around (0.5, 0.5), homogeneous Dirichlet data on both circles, manufactured solution sin(pi k r*)."""
+        npts = _i([len(c) for c in clouds])
+        xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))
+        pd = _i(polydegs)
+        f = lib().mmgh_mg_create_annulus
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        h = f(len(clouds), npts.ctypes.data_as(_ip), xyz.ctypes.data_as(_dp), pd.ctypes.data_as(_ip), int(k), ordering,
+              tile_points, float(omega), int(iters))
+        if not h:
+            raise HostError(_err())
+        return cls._from_handle(h, omega, iters)
+
     @staticmethod
     def last_setup_times():
         """Wall seconds of the stages of the last constructor call: one entry per grid (cloud -> ordering ->
@@ -620,6 +636,25 @@ def square_cloud(nside, seed=12345, jitter=0.25):
     """nside^2 lattice on [0,1]^2, interior jittered by +-jitter*h, boundary coordinates
     exactly 0/1 (the reference detects boundaries by exact compares, testing_functions.cpp:86)."""
     return box_cloud(nside, 2, seed, jitter)
+
+
+def annulus_cloud(nr, seed=12345, jitter=0.25):
+    """Point cloud of the annulus 0.25 <= r <= 0.5 around (0.5, 0.5): nr + 1 rings, spacing h = 0.25 / nr along r and
+    about h along each ring; the inner and outer ring lie ON the circles (the reference detects them by
+    |r^2 - R^2| <= 1e-10, testing_functions.cpp:124,129), the others are jittered by +-jitter*h in r and along the ring."""
+    rng = np.random.default_rng(seed)
+    h = 0.25 / nr
+    pts = []
+    for i in range(nr + 1):
+        r0 = 0.25 + i * h
+        m = max(8, int(round(2 * np.pi * r0 / h)))
+        th = 2 * np.pi * (np.arange(m) + 0.5 * (i % 2)) / m
+        r = np.full(m, r0)
+        if 0 < i < nr:
+            r = r + jitter * h * rng.uniform(-1, 1, m)
+            th = th + jitter * h / r0 * rng.uniform(-1, 1, m)
+        pts.append(np.stack([0.5 + r * np.cos(th), 0.5 + r * np.sin(th), np.zeros(m)], axis=1))
+    return np.concatenate(pts, axis=0)
 
 
 def box_cloud(nside, dim, seed=12345, jitter=0.25, edges=True):

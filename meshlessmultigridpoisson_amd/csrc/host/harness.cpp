@@ -92,6 +92,32 @@ Grid *gen_dirichlet(const double *xyz, int n, int dim, GridProperties props, int
     return g;
 }
 
+// testing_functions.cpp:68-160, geomtype "concentric_circles": annulus 0.25 <= r <= 0.5 around (0.5, 0.5), homogeneous
+// Dirichlet data on BOTH circles (two boundaries; points within 1e-10 of a circle in r^2 belong to it), manufactured
+// solution sin(pi k r*), r* = (r - 0.25) / 0.25, source = its Laplacian u'' + u'/r = -16 pi^2 k^2 sin + 4 pi k cos / r
+Grid *gen_dirichlet_annulus(const double *xyz, int n, GridProperties props, int k, int ordering, int tile_points)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n);
+    Boundary outer, inner;
+    outer.type = inner.type = 1;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]) - 0.5, y = std::get<1>(pts[(size_t)i]) - 0.5;
+        const double r2 = x * x + y * y, r = std::sqrt(r2);
+        const double rstar = (r - 0.25) / (0.5 - 0.25), a = PI_REF * k;
+        source(i) = -16.0 * a * a * std::sin(a * rstar) + 4.0 * a * std::cos(a * rstar) / r;
+        if (std::abs(0.25 - r2) <= 1e-10) { outer.bcPoints.push_back(i); outer.values.push_back(0.0); }
+        else if (std::abs(0.0625 - r2) <= 1e-10) { inner.bcPoints.push_back(i); inner.values.push_back(0.0); }
+    }
+    Grid *g = new Grid(pts, std::vector<Boundary>{outer, inner}, props, source);
+    g->dim_ = 2;
+    g->implicitFlag_ = false;
+    g->setBCFlag(0, std::string("dirichlet"), outer.values);
+    g->setBCFlag(1, std::string("dirichlet"), inner.values);
+    order_points(g, ordering, tile_points);
+    return g;
+}
+
 // testing_functions.cpp:161-284, geomtype "square"
 Grid *gen_neumann(const double *xyz, int n, int dim, GridProperties props, int k1, int k2, int ordering,
                   int tile_points, bool coarse)
@@ -169,6 +195,27 @@ void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, con
         const auto t1 = now();
         mg->buildMatrices();
         g_mg_setup_times[(size_t)nlevels] = since(t1);
+    });
+    if (rc) { delete mg; return nullptr; }
+    return mg;
+}
+
+// run_mg_sim's hierarchy on the reference's "concentric_circles" geometry (Dirichlet on both circles)
+void *mmgh_mg_create_annulus(int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
+                             int tile_points, double omega, int iters)
+{
+    Multigrid *mg = nullptr;
+    const int rc = guard([&]() {
+        mg = new Multigrid();
+        mg->printResiduals_ = false;
+        size_t off = 0;
+        for (int l = 0; l < nlevels; ++l) {
+            Grid *g = gen_dirichlet_annulus(xyz + 3 * off, npts[l], make_props(polydeg[l], 2, omega, iters), k, ordering, tile_points);
+            g->build_laplacian();
+            mg->addGrid(g);
+            off += (size_t)npts[l];
+        }
+        mg->buildMatrices();
     });
     if (rc) { delete mg; return nullptr; }
     return mg;

@@ -331,3 +331,26 @@ def test_long_row_dense_groups_match_oracle_in_every_launch_mode(host, mode):
             assert H.rel_err(r, lvo.residual()) < 1e-11
     finally:
         _capi.set_option("persistent_sweep", 1)
+
+
+def test_annulus_known_answer_on_device(host):
+    """The reference's "concentric_circles" problem on the GPU path: two Dirichlet boundaries (both scatter lists of the
+    level), V-cycles follow the CPU oracle and reach sin(pi k r*) to the discretisation error
+    (calc_l1_error_circle, testing_functions.cpp:34-67)."""
+    clouds = [host.annulus_cloud(nr, seed=12345 + i) for i, nr in enumerate([8, 16, 32])]
+    mg = host.Multigrid.annulus(clouds, [3, 3, 3], k=2, tile_points=0)
+    om = H.oracle_of_multigrid(mg)
+    _follow_oracle(mg, om, 8)
+    res, _ms = mg.vcycles(80)
+    for _ in range(80):
+        om.vcycle()
+    assert res[-1] < 1e-5 * res[0]
+    g = mg.grid(2)
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    rstar = (np.sqrt((xyz[:, 0] - 0.5) ** 2 + (xyz[:, 1] - 0.5) ** 2) - 0.25) / 0.25
+    exact = np.sin(2 * np.pi * rstar)
+    err_gpu = np.abs(g.values()[:n] - exact).sum() / n
+    err_cpu = np.abs(om.levels[-1].x[:n] - exact).sum() / n
+    assert err_gpu < 1e-2, err_gpu
+    assert abs(err_gpu - err_cpu) <= 1e-7 * max(err_cpu, 1e-12), (err_gpu, err_cpu)

@@ -256,3 +256,26 @@ def test_neumann_3d_scaled_multiplier_row_and_edge_free_cloud_converge():
     r_o, _ = lv.residual(), None
     r_e, _nrm = emu.residual()
     assert H.rel_err(r_e, r_o) < 1e-11
+
+
+def test_annulus_known_answer_two_dirichlet_boundaries():
+    """The reference's "concentric_circles" problem (testing_functions.cpp:107-135, calc_l1_error_circle :34-67): annulus
+    0.25 <= r <= 0.5, homogeneous Dirichlet data on BOTH circles (two Boundary objects), manufactured solution
+    sin(pi k r*).  Host-built three-level hierarchy, CPU oracle V-cycles: contracts, L1 error per point at the
+    discretisation level (the reference prints it; it holds no number)."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    clouds = [host.annulus_cloud(nr, seed=12345 + i) for i, nr in enumerate([6, 12, 24])]
+    r2 = (clouds[-1][:, 0] - 0.5) ** 2 + (clouds[-1][:, 1] - 0.5) ** 2
+    assert (np.abs(0.25 - r2) <= 1e-10).sum() > 100 and (np.abs(0.0625 - r2) <= 1e-10).sum() > 50
+    mg = host.Multigrid.annulus(clouds, [3, 3, 3], k=1, tile_points=128)
+    g = mg.grid(2)
+    assert g.sizes()["nb"] == 2
+    om = H.oracle_of_multigrid(mg)
+    hist = [om.vcycle() for _ in range(60)]
+    assert hist[-1] < 1e-4 * hist[0]
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    rstar = (np.sqrt((xyz[:, 0] - 0.5) ** 2 + (xyz[:, 1] - 0.5) ** 2) - 0.25) / 0.25
+    err = np.abs(om.levels[-1].x[:n] - np.sin(np.pi * rstar)).sum() / n
+    assert err < 5e-3, err                       # measured 1.3e-3 (24 rings, polyDeg 3)
