@@ -481,16 +481,26 @@ class Multigrid:
             self.h = None
 
     @classmethod
+    def square_with_circle(cls, clouds, polydegs, k=1, ordering=ORDER_MC, tile_points=0, omega=1.4, iters=5):
+        """The reference's "square_with_circle" test problem (testing_functions.cpp:85-106): unit square with a hole of
+        radius 0.25, u = 0 on the square, u = sin(k pi x) sin(k pi y) on the circle (inhomogeneous second boundary)."""
+        return cls._geom(1, clouds, polydegs, k, ordering, tile_points, omega, iters)
+
+    @classmethod
     def annulus(cls, clouds, polydegs, k=1, ordering=ORDER_MC, tile_points=0, omega=1.4, iters=5):
         """The reference's "concentric_circles" test problem (testing_functions.cpp:107-135): annulus 0.25 <= r <= 0.5
         around (0.5, 0.5), homogeneous Dirichlet data on both circles, manufactured solution sin(pi k r*)."""
+        return cls._geom(2, clouds, polydegs, k, ordering, tile_points, omega, iters)
+
+    @classmethod
+    def _geom(cls, geom, clouds, polydegs, k, ordering, tile_points, omega, iters):
         npts = _i([len(c) for c in clouds])
         xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))
         pd = _i(polydegs)
-        f = lib().mmgh_mg_create_annulus
+        f = lib().mmgh_mg_create_geom
         f.restype = C.c_void_p
-        f.argtypes = [C.c_int, _ip, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
-        h = f(len(clouds), npts.ctypes.data_as(_ip), xyz.ctypes.data_as(_dp), pd.ctypes.data_as(_ip), int(k), ordering,
+        f.argtypes = [C.c_int, C.c_int, _ip, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        h = f(int(geom), len(clouds), npts.ctypes.data_as(_ip), xyz.ctypes.data_as(_dp), pd.ctypes.data_as(_ip), int(k), ordering,
               tile_points, float(omega), int(iters))
         if not h:
             raise HostError(_err())
@@ -636,6 +646,19 @@ def square_cloud(nside, seed=12345, jitter=0.25):
     """nside^2 lattice on [0,1]^2, interior jittered by +-jitter*h, boundary coordinates
     exactly 0/1 (the reference detects boundaries by exact compares, testing_functions.cpp:86)."""
     return box_cloud(nside, 2, seed, jitter)
+
+
+def square_with_circle_cloud(nside, seed=12345, jitter=0.25):
+    """Unit square with a circular hole of radius 0.25 around (0.5, 0.5): the jittered lattice of square_cloud without
+    the points inside (or within 0.6 h of) the circle, plus a ring of points ON the circle (|r^2 - 1/16| <= 1e-10)."""
+    pts = box_cloud(nside, 2, seed, jitter)
+    h = 1.0 / (nside - 1)
+    r = np.sqrt((pts[:, 0] - 0.5) ** 2 + (pts[:, 1] - 0.5) ** 2)
+    pts = pts[r >= 0.25 + 0.6 * h]
+    m = max(8, int(round(2 * np.pi * 0.25 / h)))
+    th = 2 * np.pi * np.arange(m) / m
+    ring = np.stack([0.5 + 0.25 * np.cos(th), 0.5 + 0.25 * np.sin(th), np.zeros(m)], axis=1)
+    return np.concatenate([pts, ring], axis=0)
 
 
 def annulus_cloud(nr, seed=12345, jitter=0.25):

@@ -92,6 +92,31 @@ Grid *gen_dirichlet(const double *xyz, int n, int dim, GridProperties props, int
     return g;
 }
 
+// testing_functions.cpp:68-106, geomtype "square_with_circle": unit square with a circular hole of radius 0.25 around
+// (0.5, 0.5); outer boundary u = 0, on the circle u = the manufactured solution sin(k pi x) sin(k pi y) (the reference
+// uses k1 for both factors, :96,103), source = its Laplacian -2 k^2 pi^2 sin sin
+Grid *gen_dirichlet_square_with_circle(const double *xyz, int n, GridProperties props, int k, int ordering, int tile_points)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n);
+    Boundary outer, inner;
+    outer.type = inner.type = 1;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]), y = std::get<1>(pts[(size_t)i]);
+        const double u = std::sin(k * PI_REF * x) * std::sin(k * PI_REF * y);
+        source(i) = -(2.0 * k * k) * PI_REF * PI_REF * u;
+        if (x == 0 || x == 1 || y == 0 || y == 1) { outer.bcPoints.push_back(i); outer.values.push_back(0.0); }
+        else if (std::abs(0.0625 - (x - 0.5) * (x - 0.5) - (y - 0.5) * (y - 0.5)) <= 1e-10) { inner.bcPoints.push_back(i); inner.values.push_back(u); }
+    }
+    Grid *g = new Grid(pts, std::vector<Boundary>{outer, inner}, props, source);
+    g->dim_ = 2;
+    g->implicitFlag_ = false;
+    g->setBCFlag(0, std::string("dirichlet"), outer.values);
+    g->setBCFlag(1, std::string("dirichlet"), inner.values);
+    order_points(g, ordering, tile_points);
+    return g;
+}
+
 // testing_functions.cpp:68-160, geomtype "concentric_circles": annulus 0.25 <= r <= 0.5 around (0.5, 0.5), homogeneous
 // Dirichlet data on BOTH circles (two boundaries; points within 1e-10 of a circle in r^2 belong to it), manufactured
 // solution sin(pi k r*), r* = (r - 0.25) / 0.25, source = its Laplacian u'' + u'/r = -16 pi^2 k^2 sin + 4 pi k cos / r
@@ -201,8 +226,16 @@ void *mmgh_mg_create_square(int nlevels, const int *npts, const double *xyz, con
 }
 
 // run_mg_sim's hierarchy on the reference's "concentric_circles" geometry (Dirichlet on both circles)
+void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
+                          int tile_points, double omega, int iters);
 void *mmgh_mg_create_annulus(int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
                              int tile_points, double omega, int iters)
+{
+    return mmgh_mg_create_geom(2, nlevels, npts, xyz, polydeg, k, ordering, tile_points, omega, iters);
+}
+// geom 1: "square_with_circle", 2: "concentric_circles" (Dirichlet on both boundaries)
+void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
+                          int tile_points, double omega, int iters)
 {
     Multigrid *mg = nullptr;
     const int rc = guard([&]() {
@@ -210,7 +243,9 @@ void *mmgh_mg_create_annulus(int nlevels, const int *npts, const double *xyz, co
         mg->printResiduals_ = false;
         size_t off = 0;
         for (int l = 0; l < nlevels; ++l) {
-            Grid *g = gen_dirichlet_annulus(xyz + 3 * off, npts[l], make_props(polydeg[l], 2, omega, iters), k, ordering, tile_points);
+            GridProperties props = make_props(polydeg[l], 2, omega, iters);
+            Grid *g = geom == 1 ? gen_dirichlet_square_with_circle(xyz + 3 * off, npts[l], props, k, ordering, tile_points)
+                                : gen_dirichlet_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points);
             g->build_laplacian();
             mg->addGrid(g);
             off += (size_t)npts[l];

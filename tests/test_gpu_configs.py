@@ -354,3 +354,24 @@ def test_annulus_known_answer_on_device(host):
     err_cpu = np.abs(om.levels[-1].x[:n] - exact).sum() / n
     assert err_gpu < 1e-2, err_gpu
     assert abs(err_gpu - err_cpu) <= 1e-7 * max(err_cpu, 1e-12), (err_gpu, err_cpu)
+
+
+def test_square_with_circle_known_answer_on_device(host):
+    """The reference's "square_with_circle" problem on the GPU path: the second boundary carries non-zero Dirichlet
+    values (boundaryOp fine / coarse on the device); V-cycles follow the CPU oracle and reach sin sin."""
+    clouds = [host.square_with_circle_cloud(n, seed=12345 + i) for i, n in enumerate([21, 41, 81])]
+    mg = host.Multigrid.square_with_circle(clouds, [3, 3, 3], k=1, tile_points=0)
+    om = H.oracle_of_multigrid(mg)
+    _follow_oracle(mg, om, 8)
+    res, _ms = mg.vcycles(50)
+    for _ in range(50):
+        om.vcycle()
+    assert res[-1] < 1e-5, res[-1]
+    g = mg.grid(2)
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
+    err_gpu = np.abs(g.values()[:n] - exact).sum() / n
+    err_cpu = np.abs(om.levels[-1].x[:n] - exact).sum() / n
+    assert err_gpu < 1e-4, err_gpu
+    assert abs(err_gpu - err_cpu) <= 1e-6 * max(err_cpu, 1e-12), (err_gpu, err_cpu)

@@ -279,3 +279,24 @@ def test_annulus_known_answer_two_dirichlet_boundaries():
     rstar = (np.sqrt((xyz[:, 0] - 0.5) ** 2 + (xyz[:, 1] - 0.5) ** 2) - 0.25) / 0.25
     err = np.abs(om.levels[-1].x[:n] - np.sin(np.pi * rstar)).sum() / n
     assert err < 5e-3, err                       # measured 1.3e-3 (24 rings, polyDeg 3)
+
+
+def test_square_with_circle_known_answer_inhomogeneous_inner_boundary():
+    """The reference's "square_with_circle" problem (testing_functions.cpp:85-106): unit square with a hole of radius
+    0.25, u = 0 on the square and u = sin(k pi x) sin(k pi y) ON THE CIRCLE (a second boundary with non-zero values:
+    boundaryOp "fine" writes them, "coarse" zeroes them on the coarse levels).  CPU oracle on the host-built hierarchy."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    clouds = [host.square_with_circle_cloud(n, seed=12345 + i) for i, n in enumerate([17, 33, 65])]
+    mg = host.Multigrid.square_with_circle(clouds, [3, 3, 3], k=1, tile_points=128)
+    g = mg.grid(2)
+    assert g.sizes()["nb"] == 2
+    om = H.oracle_of_multigrid(mg)
+    hist = [om.vcycle() for _ in range(50)]
+    assert hist[-1] < 1e-7 * hist[0]
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
+    on_circle = np.abs(0.0625 - (xyz[:, 0] - 0.5) ** 2 - (xyz[:, 1] - 0.5) ** 2) <= 1e-10
+    assert on_circle.sum() > 50 and np.allclose(om.levels[-1].x[:n][on_circle], exact[on_circle], rtol=0, atol=1e-15)
+    assert np.abs(om.levels[-1].x[:n] - exact).sum() / n < 1e-4       # measured 1.0e-5
