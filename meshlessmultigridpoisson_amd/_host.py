@@ -493,6 +493,12 @@ class Multigrid:
         return cls._geom(2, clouds, polydegs, k, ordering, tile_points, omega, iters)
 
     @classmethod
+    def annulus_neumann(cls, clouds, polydegs, k=1, ordering=ORDER_MC, tile_points=0, omega=1.4, iters=5):
+        """"concentric_circles" with Neumann data on both circles (testing_functions.cpp:212-250): the normal derivative
+        of sin(pi k r*) along the inward normals, non-zero on both boundaries (push_inhomog_to_rhs)."""
+        return cls._geom(3, clouds, polydegs, k, ordering, tile_points, omega, iters)
+
+    @classmethod
     def _geom(cls, geom, clouds, polydegs, k, ordering, tile_points, omega, iters):
         npts = _i([len(c) for c in clouds])
         xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))

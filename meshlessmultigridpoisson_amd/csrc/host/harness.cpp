@@ -173,6 +173,38 @@ Grid *gen_neumann(const double *xyz, int n, int dim, GridProperties props, int k
     g->push_inhomog_to_rhs();
     return g;
 }
+// testing_functions.cpp:161-284, geomtype "concentric_circles": the annulus with Neumann data on BOTH circles -- the
+// normal derivative of sin(pi k r*) along the inward normals (build_normal_vecs: -r^ on the outer circle, +r^ on the
+// inner one): u'(r) = 4 pi k cos(pi k r*), so -u' outside and +u' inside; source as in the Dirichlet problem
+Grid *gen_neumann_annulus(const double *xyz, int n, GridProperties props, int k, int ordering, int tile_points, bool coarse)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n + 1);
+    Boundary outer, inner;
+    outer.type = inner.type = 2;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]) - 0.5, y = std::get<1>(pts[(size_t)i]) - 0.5;
+        const double r2 = x * x + y * y, r = std::sqrt(r2);
+        const double rstar = (r - 0.25) / (0.5 - 0.25), a = PI_REF * k;
+        source(i) = -16.0 * a * a * std::sin(a * rstar) + 4.0 * a * std::cos(a * rstar) / r;
+        const double du = 4.0 * a * std::cos(a * rstar);
+        if (std::abs(0.25 - r2) <= 1e-10) { outer.bcPoints.push_back(i); outer.values.push_back(-du); }
+        else if (std::abs(0.0625 - r2) <= 1e-10) { inner.bcPoints.push_back(i); inner.values.push_back(du); }
+    }
+    source(n) = 0;
+    Grid *g = new Grid(pts, std::vector<Boundary>{outer, inner}, props, source);
+    g->dim_ = 2;
+    g->implicitFlag_ = true;
+    g->setBCFlag(0, std::string("neumann"), outer.values);
+    g->setBCFlag(1, std::string("neumann"), inner.values);
+    g->build_normal_vecs("", "concentric_circles");
+    order_points(g, ordering, tile_points);
+    g->build_deriv_normal_bound();
+    g->build_laplacian();
+    g->modify_coeff_neumann(coarse ? "coarse" : "fine");
+    g->push_inhomog_to_rhs();
+    return g;
+}
 }  // namespace
 
 extern "C" {
@@ -233,7 +265,8 @@ void *mmgh_mg_create_annulus(int nlevels, const int *npts, const double *xyz, co
 {
     return mmgh_mg_create_geom(2, nlevels, npts, xyz, polydeg, k, ordering, tile_points, omega, iters);
 }
-// geom 1: "square_with_circle", 2: "concentric_circles" (Dirichlet on both boundaries)
+// geom 1: "square_with_circle", 2: "concentric_circles" (Dirichlet on both boundaries), 3: "concentric_circles" with
+// Neumann data on both circles
 void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
                           int tile_points, double omega, int iters)
 {
@@ -244,9 +277,13 @@ void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *
         size_t off = 0;
         for (int l = 0; l < nlevels; ++l) {
             GridProperties props = make_props(polydeg[l], 2, omega, iters);
-            Grid *g = geom == 1 ? gen_dirichlet_square_with_circle(xyz + 3 * off, npts[l], props, k, ordering, tile_points)
-                                : gen_dirichlet_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points);
-            g->build_laplacian();
+            Grid *g;
+            if (geom == 3) g = gen_neumann_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points, l != nlevels - 1);
+            else {
+                g = geom == 1 ? gen_dirichlet_square_with_circle(xyz + 3 * off, npts[l], props, k, ordering, tile_points)
+                              : gen_dirichlet_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points);
+                g->build_laplacian();
+            }
             mg->addGrid(g);
             off += (size_t)npts[l];
         }
