@@ -499,6 +499,12 @@ class Multigrid:
         return cls._geom(3, clouds, polydegs, k, ordering, tile_points, omega, iters)
 
     @classmethod
+    def square_with_circle_neumann(cls, clouds, polydegs, k=1, ordering=ORDER_MC, tile_points=0, omega=1.4, iters=5):
+        """"square_with_circle" with Neumann data (testing_functions.cpp:186-209): cos cos, zero normal derivative on
+        the square, its derivative along the radial normal on the circle."""
+        return cls._geom(4, clouds, polydegs, k, ordering, tile_points, omega, iters)
+
+    @classmethod
     def _geom(cls, geom, clouds, polydegs, k, ordering, tile_points, omega, iters):
         npts = _i([len(c) for c in clouds])
         xyz = _d(np.concatenate([_d(c).reshape(-1, 3) for c in clouds], axis=0))

@@ -173,6 +173,43 @@ Grid *gen_neumann(const double *xyz, int n, int dim, GridProperties props, int k
     g->push_inhomog_to_rhs();
     return g;
 }
+// testing_functions.cpp:161-284, geomtype "square_with_circle": cos cos on the unit square with a hole; zero normal
+// derivative on the square, on the circle the derivative of cos(k1 pi x) cos(k2 pi y) along +r^ (the normal pointing
+// into the domain, build_normal_vecs)
+Grid *gen_neumann_square_with_circle(const double *xyz, int n, GridProperties props, int k1, int k2, int ordering,
+                                     int tile_points, bool coarse)
+{
+    std::vector<Point> pts = to_points(xyz, n);
+    mmgh::Vec source((size_t)n + 1);
+    Boundary outer, inner;
+    outer.type = inner.type = 2;
+    for (int i = 0; i < n; ++i) {
+        const double x = std::get<0>(pts[(size_t)i]), y = std::get<1>(pts[(size_t)i]);
+        source(i) = -(k1 * k1 + k2 * k2) * PI_REF * PI_REF * std::cos(k1 * PI_REF * x) * std::cos(k2 * PI_REF * y);
+        if (x == 0 || x == 1 || y == 0 || y == 1) { outer.bcPoints.push_back(i); outer.values.push_back(0.0); }
+        else if (std::abs(0.0625 - (x - 0.5) * (x - 0.5) - (y - 0.5) * (y - 0.5)) <= 1e-10) {
+            const double nx = (x - 0.5) / 0.25, ny = (y - 0.5) / 0.25;
+            const double ux = -k1 * PI_REF * std::sin(k1 * PI_REF * x) * std::cos(k2 * PI_REF * y);
+            const double uy = -k2 * PI_REF * std::cos(k1 * PI_REF * x) * std::sin(k2 * PI_REF * y);
+            inner.bcPoints.push_back(i);
+            inner.values.push_back(nx * ux + ny * uy);
+        }
+    }
+    source(n) = 0;
+    Grid *g = new Grid(pts, std::vector<Boundary>{outer, inner}, props, source);
+    g->dim_ = 2;
+    g->implicitFlag_ = true;
+    g->setBCFlag(0, std::string("neumann"), outer.values);
+    g->setBCFlag(1, std::string("neumann"), inner.values);
+    g->build_normal_vecs("", "square_with_circle");
+    order_points(g, ordering, tile_points);
+    g->build_deriv_normal_bound();
+    g->build_laplacian();
+    g->modify_coeff_neumann(coarse ? "coarse" : "fine");
+    g->push_inhomog_to_rhs();
+    return g;
+}
+
 // testing_functions.cpp:161-284, geomtype "concentric_circles": the annulus with Neumann data on BOTH circles -- the
 // normal derivative of sin(pi k r*) along the inward normals (build_normal_vecs: -r^ on the outer circle, +r^ on the
 // inner one): u'(r) = 4 pi k cos(pi k r*), so -u' outside and +u' inside; source as in the Dirichlet problem
@@ -266,7 +303,7 @@ void *mmgh_mg_create_annulus(int nlevels, const int *npts, const double *xyz, co
     return mmgh_mg_create_geom(2, nlevels, npts, xyz, polydeg, k, ordering, tile_points, omega, iters);
 }
 // geom 1: "square_with_circle", 2: "concentric_circles" (Dirichlet on both boundaries), 3: "concentric_circles" with
-// Neumann data on both circles
+// Neumann data on both circles, 4: "square_with_circle" with Neumann data (k = k1 = k2)
 void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *xyz, const int *polydeg, int k, int ordering,
                           int tile_points, double omega, int iters)
 {
@@ -279,6 +316,7 @@ void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *
             GridProperties props = make_props(polydeg[l], 2, omega, iters);
             Grid *g;
             if (geom == 3) g = gen_neumann_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points, l != nlevels - 1);
+            else if (geom == 4) g = gen_neumann_square_with_circle(xyz + 3 * off, npts[l], props, k, k, ordering, tile_points, l != nlevels - 1);
             else {
                 g = geom == 1 ? gen_dirichlet_square_with_circle(xyz + 3 * off, npts[l], props, k, ordering, tile_points)
                               : gen_dirichlet_annulus(xyz + 3 * off, npts[l], props, k, ordering, tile_points);

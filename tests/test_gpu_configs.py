@@ -402,3 +402,28 @@ def test_annulus_neumann_known_answer_on_device(host):
     err_gpu, err_cpu = l1_after_shift(g.values()), l1_after_shift(om.levels[-1].x)
     assert err_gpu < 2e-3, err_gpu            # measured 6.4e-4 (3.0e-3 after 120 cycles: the slow tail)
     assert abs(err_gpu - err_cpu) <= 1e-6 * max(err_cpu, 1e-12), (err_gpu, err_cpu)
+
+
+def test_square_with_circle_neumann_known_answer_on_device(host):
+    """The reference's Neumann problem on "square_with_circle" on the GPU path (mixed face / radial normals, non-zero
+    data on the circle): follows the CPU oracle, reaches cos cos after the mean shift."""
+    clouds = [host.square_with_circle_cloud(n, seed=12345 + i) for i, n in enumerate([33, 65])]
+    mg = host.Multigrid.square_with_circle_neumann(clouds, [3, 3], k=1, tile_points=0)
+    om = H.oracle_of_multigrid(mg)
+    _follow_oracle(mg, om, 10)
+    res, _ms = mg.vcycles(190)
+    for _ in range(190):
+        om.vcycle()
+    assert res[-1] < 2e-4
+    g = mg.grid(1)
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    exact = np.cos(np.pi * xyz[:, 0]) * np.cos(np.pi * xyz[:, 1])
+
+    def l1_after_shift(values):
+        u = values[:n] + (exact.mean() - values[:n].mean())
+        return np.abs(u - exact).sum() / n
+
+    err_gpu, err_cpu = l1_after_shift(g.values()), l1_after_shift(om.levels[-1].x)
+    assert err_gpu < 5e-4, err_gpu
+    assert abs(err_gpu - err_cpu) <= 1e-6 * max(err_cpu, 1e-12), (err_gpu, err_cpu)

@@ -324,3 +324,21 @@ def test_annulus_neumann_known_answer_inhomogeneous_data_on_curved_boundaries():
     v = om.levels[-1].x[:n]
     err = np.abs(v + (exact.mean() - v.mean()) - exact).sum() / n
     assert err < 2e-3, err                       # measured 6.4e-4 after 200 cycles (3.0e-3 after 120: the slow tail)
+
+
+def test_square_with_circle_neumann_known_answer():
+    """The reference's Neumann run on "square_with_circle" (testing_functions.cpp:186-209): face normals on the square,
+    radial normals on the circle, non-zero data on the circle only.  Two levels, CPU oracle; cos cos after the mean shift."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    clouds = [host.square_with_circle_cloud(n, seed=12345 + i) for i, n in enumerate([33, 65])]
+    mg = host.Multigrid.square_with_circle_neumann(clouds, [3, 3], k=1, tile_points=128)
+    g = mg.grid(1)
+    om = H.oracle_of_multigrid(mg)
+    hist = [om.vcycle() for _ in range(200)]
+    assert hist[-1] < 2e-4 * hist[0]
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    exact = np.cos(np.pi * xyz[:, 0]) * np.cos(np.pi * xyz[:, 1])
+    v = om.levels[-1].x[:n]
+    assert np.abs(v + (exact.mean() - v.mean()) - exact).sum() / n < 5e-4       # measured 6.8e-5
