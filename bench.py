@@ -196,6 +196,7 @@ def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
            "fine_Mpoints_per_s": sides[-1] ** dim / (per * 1e-3) / 1e6,
            "layout": [{k: lv[k] for k in ("n", "tiles", "lanes_per_row", "waves_per_tile")} for lv in levels],
            "residual_history_first_cycles": [float(r) for r in mg.residuals[:4]],
+           "contraction_per_cycle_timed_cycles": float((res[-1] / res[0]) ** (1.0 / max(1, len(res) - 1))) if len(res) > 1 and res[0] > 0 else None,
            "tolerance_vs_cpu_oracle": "1e-10 relative for rho >= 2e-3, 2e-13 absolute below (evaluation noise of rho); "
                                       "exact-arithmetic mode bitwise (tests/test_gpu_parity.py, tests/test_gpu_configs.py)",
            "sweep_fallbacks": _capi.get_counter("sweep_fallbacks")}
