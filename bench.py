@@ -177,8 +177,15 @@ def algorithmic_bytes_per_vcycle(levels, k_interp, iters):
 def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
     """Time `cycles` device-resident V-cycles of a host Multigrid (after 3 warm-up cycles)."""
     from meshlessmultigridpoisson_amd import _capi, _host
-    mg.vcycles(3)
-    res, ms = mg.vcycles(cycles)
+    # the cycle body replayed as a HIP graph: one launch per cycle from the host instead of ~60 -- the same kernels, the
+    # same bits (tests/test_gpu_configs.py), the same time on a quiet host, but no starvation of the small-level
+    # kernels when the host is busy (a 2-D cycle measured 3.3 instead of 2.85 ms on such a box without it)
+    _capi.set_option("vcycle_graph", 1)
+    try:
+        mg.vcycles(3)
+        res, ms = mg.vcycles(cycles)
+    finally:
+        _capi.set_option("vcycle_graph", 0)
     levels = []
     for l in range(mg.nlevels):
         g = mg.grid(l)
