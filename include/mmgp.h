@@ -246,6 +246,11 @@ void mmg_hierarchy_destroy(mmg_hierarchy *h);
  * total.  The prolongation out of the replicated level needs no exchange (its input is complete everywhere).
  * Collective in effect (every rank registers the same lists). */
 int mmg_hierarchy_set_gather(mmg_hierarchy *h, int level, int nranks, int max_count, const int *gid_all, int n_global);
+/* NOT in the reference (opt-in safeguard): the coarse-grid correction is scaled by theta before it is added,
+ * x_f += theta * mask(P x_c) (multigrid.cpp:102-106 has theta = 1, the default).  The reference's cycle diverges on
+ * Neumann hierarchies of three and more levels and on large irregular 2-D clouds at omega = 1.4; with theta = 0.7 it
+ * contracts there.  0 < theta <= 1. */
+int mmg_hierarchy_set_correction_damping(mmg_hierarchy *h, double theta);
 /* Multigrid::vCycle  multigrid.cpp:62-110 ; *resid_before = residuals_.back()
  * (-1 for the frac-step single-grid early-out, which pushes nothing) */
 int mmg_vcycle(mmg_hierarchy *h, double *resid_before);

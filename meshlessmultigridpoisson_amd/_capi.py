@@ -54,6 +54,7 @@ SYMBOLS = [
     "mmg_fracstep_apply_bound", "mmg_fracstep_step", "mmg_level_set_neumann_coupling", "mmg_level_push_inhomog_to_rhs",
     "mmg_hierarchy_set_gather",
     "mmg_knn",
+    "mmg_hierarchy_set_correction_damping",
     "mmg_host_threads",
     "mmg_rbf_stencils",
 ]

@@ -518,6 +518,13 @@ class Multigrid:
             raise HostError(_err())
         return cls._from_handle(h, omega, iters)
 
+    def set_correction_damping(self, theta):
+        """NOT in the reference (opt-in safeguard): x_f += theta * P x_c instead of the plain coarse-grid correction."""
+        f = lib().mmgh_mg_set_correction_damping
+        f.argtypes = [C.c_void_p, C.c_double]
+        _chk(f(self.h, float(theta)))
+        self.damping = float(theta)
+
     @staticmethod
     def last_setup_times():
         """Wall seconds of the stages of the last constructor call: one entry per grid (cloud -> ordering ->

@@ -315,6 +315,7 @@ struct mmg_hierarchy {
     std::vector<mmg_level *> lv;
     std::vector<mmg_transfer *> R, P;
     int frac_step = 0;
+    double damping = 1.0;     // factor on the coarse-grid correction (mmg_hierarchy_set_correction_damping; the reference: 1)
     DevBuf<double> x_backup;  // fine-level x at the start of the unchecked cycle body
     bool unsettled = false;   // the last cycle body used dependency-driven launches and has not been checked yet
     // Replicated coarse levels (mmg_hierarchy_set_gather): levels below `gather_level` are complete copies on
@@ -791,7 +792,7 @@ int do_restrict(mmg_level *fine, mmg_level *coarse, mmg_transfer *R, mmg_hierarc
     return MMG_OK;
 }
 
-int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
+int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P, double theta = 1.0)
 {
     if (P->rows != fine->n || P->cols != coarse->n) return fail(MMG_ERR_INVALID, "prolong: shape mismatch");
     PlanGpu *plan = &P->all;
@@ -825,6 +826,7 @@ int do_prolong(mmg_level *coarse, mmg_level *fine, mmg_transfer *P)
     a.n_list = plan->n_tiles;
     a.in = coarse->x.p;
     a.out = fine->x.p;
+    a.add_scale = theta;  // 1: the reference's correction (multigrid.cpp:102-106)
     HIPC(run_tiles(*plan, MODE_ADD, a, g_stream));
     return MMG_OK;
 }
@@ -851,7 +853,7 @@ int cycle_body(mmg_hierarchy *h)
     if ((rc = sweeps(curr, curr->iters))) return rc;
     for (int i = 1; i < nl; ++i) {  // :99-109
         curr = h->lv[i];
-        if ((rc = do_prolong(h->lv[i - 1], curr, h->P[i - 1]))) return rc;
+        if ((rc = do_prolong(h->lv[i - 1], curr, h->P[i - 1], h->damping))) return rc;
         if ((rc = sweeps(curr, curr->iters))) return rc;
     }
     return MMG_OK;
@@ -1711,6 +1713,16 @@ int mmg_hierarchy_residual(mmg_hierarchy *h, double *ratio)
     if (rc || (rc = settle(h->lv.back()))) return rc;
     return residual_ratio(h->lv.back(), ratio);
 }
+int mmg_hierarchy_set_correction_damping(mmg_hierarchy *h, double theta)
+{
+    if (!h || !(theta > 0.0) || theta > 1.0) return fail(MMG_ERR_INVALID, "correction damping: 0 < theta <= 1");
+    int rc = settle_hierarchy(h);
+    if (rc) return rc;
+    h->damping = theta;
+    ++g_state_gen;  // a captured cycle body carries the old factor in its kernel arguments
+    return MMG_OK;
+}
+
 int mmg_vcycles(mmg_hierarchy *h, int ncycles, double *resid, float *ms)
 {
     if (!h || ncycles < 0) return fail(MMG_ERR_INVALID, "bad argument");

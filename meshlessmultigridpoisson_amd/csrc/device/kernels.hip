@@ -316,7 +316,7 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
             } else if (MODE == MODE_SET) {
                 a.out[m.gid] = acc;
             } else {
-                a.out[m.gid] += acc;
+                a.out[m.gid] += (a.add_scale == 0.0 ? 1.0 : a.add_scale) * acc;
             }
         }
     };
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) void tile_kernel_exact(TileArgs a)
             } else if (MODE == MODE_SET) {
                 a.out[m.gid] = acc;
             } else {
-                a.out[m.gid] = a.out[m.gid] + acc;
+                a.out[m.gid] = a.out[m.gid] + (a.add_scale == 0.0 ? 1.0 : a.add_scale) * acc;
             }
         }
         p += group_bytes_dev(1, nr, plen);

@@ -54,6 +54,7 @@ struct TileArgs {
     int n_sweeps;              // sweeps fused into this launch (tickets run over n_sweeps * n_list)
     unsigned *error;           // device word, set to 1 when a dependency wait runs out of polls (wait_for_tiles)
     int spin_bound;            // polls per dependency wait (default 1 << 22; option "debug_spin_bound")
+    double add_scale;          // MODE_ADD: out += add_scale * (row sum); 0 means 1 (multigrid.cpp:102-106 adds the plain sum)
     int fence;                 // 1: add agent-scope acquire/release fences around every tile
     int resid_lds;             // RESID over a level plan: keep r in LDS, write the own range back coalesced
     const double *zeros;       // >= 512 B of zeros in global memory (set by the launch wrappers)

@@ -331,6 +331,10 @@ void *mmgh_mg_create_geom(int geom, int nlevels, const int *npts, const double *
     return mg;
 }
 
+int mmgh_mg_set_correction_damping(void *h, double theta)
+{
+    return guard([&]() { static_cast<Multigrid *>(h)->setCorrectionDamping(theta); });
+}
 void mmgh_mg_destroy(void *h) { delete static_cast<Multigrid *>(h); }
 int mmgh_mg_nlevels(void *h) { return (int)static_cast<Multigrid *>(h)->grids_.size(); }
 void *mmgh_mg_grid(void *h, int l) { return static_cast<Multigrid *>(h)->grids_.at((size_t)l).second; }

@@ -141,6 +141,14 @@ void Multigrid::ensure_device()
     std::vector<mmg_level *> lv;
     for (auto &g : grids_) lv.push_back(g.second->device());
     dev_check(mmg_hierarchy_create(&devH_, lv.data(), (int)nl, devR_.data(), devP_.data(), fracStep_ ? 1 : 0), "mmg_hierarchy_create");
+    if (correctionDamping_ != 1.0)
+        dev_check(mmg_hierarchy_set_correction_damping(devH_, correctionDamping_), "mmg_hierarchy_set_correction_damping");
+}
+
+void Multigrid::setCorrectionDamping(double theta)
+{
+    correctionDamping_ = theta;
+    if (devH_) dev_check(mmg_hierarchy_set_correction_damping(devH_, theta), "mmg_hierarchy_set_correction_damping");
 }
 
 void Multigrid::sync_all() { for (auto &g : grids_) g.second->sync_to_device(); }

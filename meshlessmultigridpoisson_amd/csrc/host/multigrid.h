@@ -21,6 +21,10 @@ public:
     vector<double> residuals_;
     bool fracStep_ = false;      // FracStepMultigrid.cpp semantics (:23, :64-67, no print)
     bool printResiduals_ = true; // multigrid.cpp:69 prints every cycle
+    // NOT in the reference (opt-in): factor on the coarse-grid correction, x_f += theta * P x_c (multigrid.cpp:102-106 is
+    // theta = 1).  0.7 makes the multi-level Neumann cycles and the large 2-D hierarchies contract that diverge at 1.
+    double correctionDamping_ = 1.0;
+    void setCorrectionDamping(double theta);
 
     Multigrid();
     virtual ~Multigrid();

@@ -214,6 +214,15 @@ void orc_csc_spmv(const orc_csc *m, const double *x, double *y)
 double orc_vcycle(orc_level *lv, int nl, const orc_csc *R, const orc_csc *P,
                   int frac_step)
 {
+    return orc_vcycle_damped(lv, nl, R, P, frac_step, 1.0);
+}
+
+/* The same cycle with the coarse-grid correction scaled by theta before it is added (multigrid.cpp:102-106 has
+ * theta = 1): not in the reference; an opt-in safeguard under which the multi-level Neumann
+ * cycles and the large 2-D hierarchies, which diverge with theta = 1, contract. */
+double orc_vcycle_damped(orc_level *lv, int nl, const orc_csc *R, const orc_csc *P,
+                         int frac_step, double theta)
+{
     orc_level *fine = &lv[nl - 1];
     if (frac_step && nl == 1) { orc_sor(fine); return -1.0; }
 
@@ -253,7 +262,7 @@ double orc_vcycle(orc_level *lv, int nl, const orc_csc *R, const orc_csc *P,
         curr = &lv[i];
         orc_csc_spmv(&P[i - 1], lv[i - 1].x, tmp);
         if (!curr->neumann_flag) orc_fix_vector_bound_coarse(curr, tmp);
-        for (int k = 0; k < curr->n; ++k) curr->x[k] += tmp[k];
+        for (int k = 0; k < curr->n; ++k) curr->x[k] += theta * tmp[k];
         orc_sor(curr);
     }
     free(work);

@@ -67,6 +67,7 @@ void orc_csc_spmv(const orc_csc *m, const double *x, double *y);
  * into residuals_); returns -1 for the frac-step single-grid early-out. */
 double orc_vcycle(orc_level *levels, int nlevels, const orc_csc *R,
                   const orc_csc *P, int frac_step);
+double orc_vcycle_damped(orc_level *levels, int nlevels, const orc_csc *R, const orc_csc *P, int frac_step, double theta);
 
 /* Block-hybrid schedule used by the multi-GPU "fast" mode: the rows are split
  * into `nparts` owner ranges by part[i]; within a sweep a row sees the CURRENT

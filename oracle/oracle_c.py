@@ -56,6 +56,8 @@ def lib(fast=False):
         L = C.CDLL(path)
         L.orc_vcycle.restype = C.c_double
         L.orc_vcycle.argtypes = [C.POINTER(_Level), C.c_int, C.POINTER(_Csc), C.POINTER(_Csc), C.c_int]
+        L.orc_vcycle_damped.restype = C.c_double
+        L.orc_vcycle_damped.argtypes = [C.POINTER(_Level), C.c_int, C.POINTER(_Csc), C.POINTER(_Csc), C.c_int, C.c_double]
         L.orc_mg_residual.restype = C.c_double
         L.orc_mg_residual.argtypes = [C.POINTER(_Level), _dp]
         L.orc_l1.restype = C.c_double
@@ -226,7 +228,9 @@ class Multigrid:
         Rs = (_Csc * nl)(*[r.struct() for r in self.R])
         Ps = (_Csc * nl)(*[p.struct() for p in self.P])
         fast = self.levels[0].fast
-        r = float(lib(fast).orc_vcycle(lv, nl, Rs, Ps, int(self.frac_step)))
+        theta = float(getattr(self, "damping", 1.0))
+        r = float(lib(fast).orc_vcycle(lv, nl, Rs, Ps, int(self.frac_step)) if theta == 1.0
+                  else lib(fast).orc_vcycle_damped(lv, nl, Rs, Ps, int(self.frac_step), theta))
         if r >= 0:
             self.residuals.append(r)
         return r

@@ -100,7 +100,9 @@ def oracle_of_multigrid(mg):
         t = mg.transfer("P", l)
         if t:
             P[l] = oc.Transfer.from_dict(t)
-    return oc.Multigrid(levels, R, P, frac_step=bool(getattr(mg, "frac_step", False)))
+    om = oc.Multigrid(levels, R, P, frac_step=bool(getattr(mg, "frac_step", False)))
+    om.damping = float(getattr(mg, "damping", 1.0))     # Multigrid.set_correction_damping (opt-in, not in the reference)
+    return om
 
 
 def oracle_of_fracstep(g):

@@ -427,3 +427,23 @@ def test_square_with_circle_neumann_known_answer_on_device(host):
     err_gpu, err_cpu = l1_after_shift(g.values()), l1_after_shift(om.levels[-1].x)
     assert err_gpu < 5e-4, err_gpu
     assert abs(err_gpu - err_cpu) <= 1e-6 * max(err_cpu, 1e-12), (err_gpu, err_cpu)
+
+
+def test_damped_coarse_correction_on_device(host):
+    """mmg_hierarchy_set_correction_damping (opt-in, not in the reference): the device cycle with theta = 0.7 follows
+    orc_vcycle_damped on a four-level Neumann hierarchy -- whose plain cycle diverges -- and contracts; theta = 1 set
+    explicitly changes no bit with respect to the default."""
+    clouds = [host.square_cloud(n, seed=777 + i) for i, n in enumerate([13, 25, 49, 97])]
+    mg = host.Multigrid(clouds, [3] * 4, neumann=True, ordering=host.ORDER_MC, tile_points=0)
+    mg.set_correction_damping(0.7)
+    om = H.oracle_of_multigrid(mg)
+    assert om.damping == 0.7
+    _follow_oracle(mg, om, 10)
+    res, _ms = mg.vcycles(40)
+    assert res[-1] < 2e-2 and res[-1] < res[-5]
+    a = host.Multigrid(clouds[2:], [3, 3], neumann=True, ordering=host.ORDER_MC, tile_points=0)
+    b = host.Multigrid(clouds[2:], [3, 3], neumann=True, ordering=host.ORDER_MC, tile_points=0)
+    b.set_correction_damping(1.0)
+    ra = [a.vcycle() for _ in range(4)]
+    rb = [b.vcycle() for _ in range(4)]
+    assert ra == rb and np.array_equal(a.grid(1).values(), b.grid(1).values())

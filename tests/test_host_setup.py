@@ -342,3 +342,21 @@ def test_square_with_circle_neumann_known_answer():
     exact = np.cos(np.pi * xyz[:, 0]) * np.cos(np.pi * xyz[:, 1])
     v = om.levels[-1].x[:n]
     assert np.abs(v + (exact.mean() - v.mean()) - exact).sum() / n < 5e-4       # measured 6.8e-5
+
+
+def test_damped_coarse_correction_makes_multilevel_neumann_contract():
+    """Opt-in safeguard, NOT in the reference: x_f += theta * P x_c.  With theta = 1 (multigrid.cpp:102-106) the
+    four-level Neumann cycle on 13^2 ... 97^2 diverges (x 30 per cycle); with theta = 0.7 it contracts.  CPU oracle
+    (orc_vcycle_damped; theta = 1 is bitwise orc_vcycle)."""
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("device_setup", 0)
+    clouds = [host.square_cloud(n, seed=777 + i) for i, n in enumerate([13, 25, 49, 97])]
+    mg = host.Multigrid(clouds, [3] * 4, neumann=True, ordering=host.ORDER_MC, tile_points=128)
+    plain = H.oracle_of_multigrid(mg)
+    hist = [plain.vcycle() for _ in range(12)]
+    assert hist[-1] > 1e3 * hist[0]                              # the reference's cycle: divergent here (x 30 per 5 cycles)
+    mg2 = host.Multigrid(clouds, [3] * 4, neumann=True, ordering=host.ORDER_MC, tile_points=128)
+    mg2.damping = 0.7
+    damped = H.oracle_of_multigrid(mg2)
+    hist = [damped.vcycle() for _ in range(40)]
+    assert hist[-1] < 2e-2 * hist[0] and hist[-1] < hist[-5], hist[-6:]
