@@ -9,11 +9,14 @@ from meshlessmultigridpoisson_amd import _host as host  # noqa: E402
 sides = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "54,108").split(",")]
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ncyc = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+theta = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 host.set_option("device_setup", 1)
 t = time.perf_counter()
 clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate(sides)]
 mg = host.Multigrid(clouds, [deg] * len(sides), dim=3, neumann=True, ordering=host.ORDER_MC, tile_points=0)
 print(f"setup {time.perf_counter() - t:.1f} s, points {[len(c) for c in clouds]}", flush=True)
+if theta != 1.0:
+    mg.set_correction_damping(theta)
 res, ms = mg.vcycles(3)
 res, ms = mg.vcycles(ncyc)
 print(f"{ms / ncyc:.3f} ms per V-cycle; residual history (every 5th): {[f'{r:.2e}' for r in res[::5]]}")
