@@ -217,6 +217,7 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     vector<vector<int>> extra = extras_of(rank);
     Multigrid *out = fracStep_ ? new FractionalStepMultigrid() : new Multigrid();
     out->printResiduals_ = printResiduals_;
+    out->correctionDamping_ = correctionDamping_;
     vector<vector<int>> loc(nl);
     for (size_t l = 0; l < nl; ++l) {
         Grid *g = grids_[l].second->extract_subdomain(part[l], rank, &extra[l]);
