@@ -4,6 +4,7 @@ Plumbing for tests and bench.py; no compute happens in Python."""
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -665,6 +666,89 @@ def square_cloud(nside, seed=12345, jitter=0.25):
     """nside^2 lattice on [0,1]^2, interior jittered by +-jitter*h, boundary coordinates
     exactly 0/1 (the reference detects boundaries by exact compares, testing_functions.cpp:86)."""
     return box_cloud(nside, 2, seed, jitter)
+
+
+# ---- reference-shaped ("Gmsh-like") clouds ---------------------------------------------------
+# The reference's inputs are Gmsh triangulations (testing_functions.cpp:355-364): evenly spaced nodes on the boundary
+# curves, a quasi-uniform interior whose first layer sits about one triangle height (0.87 h) off the boundary, and a
+# node on the bisector of every corner.  The generators below reproduce those three properties deterministically in
+# O(N); DESIGN section 2 shows why they matter (the one-sided Neumann stencils plus the implicit elimination are
+# stable on such clouds for polyDeg 3-6 and not on lattices / clipped packings).
+def _hex_rows(lo, hi, h):
+    """Hexagonally packed points of the square [lo, hi]^2: an ODD number of rows (spacing ~ 0.87 h), full rows
+    lo..hi alternating with rows shifted by half a spacing -- first and last row are full rows, so each of the four
+    corners (lo|hi, lo|hi) holds a point: the cloud is symmetric about the diagonals of the square's corners."""
+    rows = max(3, int(round((hi - lo) / (h * math.sqrt(3.0) / 2.0))) + 1)
+    rows += 1 - rows % 2
+    m = max(2, int(round((hi - lo) / h)) + 1)
+    ys = lo + (hi - lo) * np.arange(rows) / (rows - 1)
+    xe = lo + (hi - lo) * np.arange(m) / (m - 1)
+    xo = lo + (hi - lo) * (np.arange(m - 1) + 0.5) / (m - 1)
+    ne, no = (rows + 1) // 2, rows // 2
+    X = np.concatenate([np.tile(xe, ne), np.tile(xo, no)])
+    Y = np.concatenate([np.repeat(ys[0::2], m), np.repeat(ys[1::2], m - 1)])
+    return X, Y
+
+
+def _square_boundary(nside):
+    """4 (nside - 1) evenly spaced nodes on the unit square, coordinates exactly 0 / 1 on the sides
+    (the reference's boundary test is `x==0||x==1||y==0||y==1`, testing_functions.cpp:86,180)."""
+    t = np.arange(nside) * (1.0 / (nside - 1))
+    t[-1] = 1.0
+    z, o = np.zeros(nside), np.ones(nside)
+    bx = np.concatenate([t, t, z[1:-1], o[1:-1]])
+    by = np.concatenate([z, o, t[1:-1], t[1:-1]])
+    return bx, by
+
+
+def quasi_uniform_square_cloud(nside, offset=0.8):
+    """Gmsh-like cloud of the unit square with boundary spacing h = 1 / (nside - 1): evenly spaced boundary nodes,
+    hexagonally packed interior kept `offset` h off the boundary, a node on every corner bisector.  About
+    1.155 (nside - 2)^2 + 4 (nside - 1) points.  Boundary nodes first."""
+    h = 1.0 / (nside - 1)
+    bx, by = _square_boundary(nside)
+    X, Y = _hex_rows(offset * h, 1.0 - offset * h, h)
+    x, y = np.concatenate([bx, X]), np.concatenate([by, Y])
+    return np.stack([x, y, np.zeros(len(x))], axis=1)
+
+
+def _ring(r0, m, phase=0.0):
+    th = 2.0 * np.pi * (np.arange(m) + phase) / m
+    return 0.5 + r0 * np.cos(th), 0.5 + r0 * np.sin(th)
+
+
+def quasi_uniform_square_with_circle_cloud(nside, offset=0.8):
+    """Gmsh-like cloud of the reference's "square_with_circle" geometry (unit square minus the disc of radius 0.25
+    around (0.5, 0.5), testing_functions.cpp:85-106,186-209): evenly spaced nodes on the square and ON the circle
+    (|r^2 - 1/16| <= 1e-10), one conforming ring of interior nodes `offset` h outside the circle (staggered against
+    the circle's nodes), hexagonal packing beyond it."""
+    h = 1.0 / (nside - 1)
+    bx, by = _square_boundary(nside)
+    m = max(8, int(round(2 * np.pi * 0.25 / h)))
+    cx, cy = _ring(0.25, m)
+    r1 = 0.25 + offset * h
+    lx, ly = _ring(r1, max(8, int(round(2 * np.pi * r1 / h))), 0.5)
+    X, Y = _hex_rows(offset * h, 1.0 - offset * h, h)
+    keep = np.sqrt((X - 0.5) ** 2 + (Y - 0.5) ** 2) >= r1 + 0.75 * h
+    x = np.concatenate([bx, cx, lx, X[keep]])
+    y = np.concatenate([by, cy, ly, Y[keep]])
+    return np.stack([x, y, np.zeros(len(x))], axis=1)
+
+
+def quasi_uniform_annulus_cloud(nr):
+    """Gmsh-like cloud of the reference's "concentric_circles" geometry (0.25 <= r <= 0.5 around (0.5, 0.5),
+    testing_functions.cpp:107-135,212-250): nr + 1 concentric rings, radial spacing 0.25 / nr = one triangle height,
+    node spacing h = that / 0.866 along every ring, consecutive rings staggered; inner and outer ring ON the circles."""
+    hr = 0.25 / nr
+    h = hr / (math.sqrt(3.0) / 2.0)
+    xs, ys = [], []
+    for i in range(nr + 1):
+        r0 = 0.25 + i * hr if i < nr else 0.5
+        x, y = _ring(r0, max(8, int(round(2 * np.pi * r0 / h))), 0.5 * (i % 2))
+        xs.append(x)
+        ys.append(y)
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    return np.stack([x, y, np.zeros(len(x))], axis=1)
 
 
 def square_with_circle_cloud(nside, seed=12345, jitter=0.25):

@@ -521,6 +521,31 @@ def square_cloud(nside, seed=12345, jitter=0.25):
     return np.array(pts)
 
 
+def quasi_uniform_square_cloud(nside, offset=0.8):
+    """Reference-shaped ("Gmsh-like") cloud of the unit square: the reference reads Gmsh triangulations
+    (testing_functions.cpp:355-364) -- evenly spaced boundary nodes (coordinates exactly 0 / 1, :86,180), a
+    quasi-uniform interior whose first layer lies about one triangle height off the boundary, a node on every
+    corner bisector.  Here: boundary spacing h = 1/(nside-1); hexagonal packing of [offset*h, 1-offset*h]^2 with an
+    ODD number of rows so that first and last row are full rows (a point at each of the four inner corners).
+    Same point set as the product's `_host.quasi_uniform_square_cloud` (tests/test_host_setup.py)."""
+    h = 1.0 / (nside - 1)
+    t = [i * h for i in range(nside)]
+    t[-1] = 1.0
+    pts = [(x, 0.0, 0.0) for x in t] + [(x, 1.0, 0.0) for x in t]
+    pts += [(0.0, y, 0.0) for y in t[1:-1]] + [(1.0, y, 0.0) for y in t[1:-1]]
+    lo, hi = offset * h, 1.0 - offset * h
+    rows = max(3, int(round((hi - lo) / (h * math.sqrt(3.0) / 2.0))) + 1)
+    rows += 1 - rows % 2
+    m = max(2, int(round((hi - lo) / h)) + 1)
+    for r in range(0, rows, 2):
+        y = lo + (hi - lo) * r / (rows - 1)
+        pts += [(lo + (hi - lo) * k / (m - 1), y, 0.0) for k in range(m)]
+    for r in range(1, rows, 2):
+        y = lo + (hi - lo) * r / (rows - 1)
+        pts += [(lo + (hi - lo) * (k + 0.5) / (m - 1), y, 0.0) for k in range(m - 1)]
+    return np.array(pts)
+
+
 def make_props(poly_deg, omega=1.4, iters=5):
     """testing_functions.cpp:372-380."""
     return GridProperties(rbfExp=3, polyDeg=poly_deg, stencilSize=stencil_size(poly_deg), omega=omega, iters=iters)
