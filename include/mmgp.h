@@ -124,6 +124,8 @@ int mmg_get_counter(const char *name, long long *value);
  * iterates and residual histories are then bitwise those of the sequential CPU loops
  * (grid.cpp:104-151, multigrid.cpp:62-115).  Slow; proves the schedule is the
  * reference's Gauss-Seidel order.
+ * "debug_fail_graph" (0/1): test hook -- the next instantiation of a captured V-cycle body "fails", the body is
+ * issued with plain launches from then on (continuing from the flag epochs in front of the failed capture).
  * "waves_per_tile": layout of levels created afterwards whose descriptor leaves it 0 -- 0 automatic (by
  * level size and stencil width), 1 packed stream, 2 / 3 / 4 / 6 dense multi-wavefront layout.
  * "vcycle_graph" (default 0): 1: after one plain run the body of mmg_vcycle (everything after the residual
@@ -301,8 +303,12 @@ int mmg_host_threads(void);
  * k smallest (distance, index) pairs of query e over the cloud, ascending (distance = sqrt(dx*dx + dy*dy
  * [+ dz*dz]) evaluated in that order, as the reference's `distance`).  For a query with query_flag != 0 the
  * candidates with cloud_flag != 0 are skipped unless their distance is exactly 0 (a Neumann grid's boundary
- * point ignores the other boundary points, grid.cpp:224,236,244); both flag arrays may be NULL.  -1 fills the
- * tail of a row when the cloud holds fewer than k candidates.  k <= 256.  Uniform cell grid + one wavefront
+ * point ignores the other boundary points, grid.cpp:224,236,244); both flag arrays may be NULL.
+ * DEVIATION, coincident points only: the reference exempts ONE zero-distance candidate, `samePoint` = the LAST index
+ * at distance 0 (grid.cpp:219-226); here EVERY flagged candidate at distance exactly 0 is kept.  The two differ only
+ * on clouds that hold several boundary points at identical coordinates (their Neumann rows would be identical and the
+ * operator singular); tests/test_gpu_setup.py pins the rule on such a cloud against a restatement of grid.cpp:216-260.
+ * -1 fills the tail of a row when the cloud holds fewer than k candidates.  k <= 256.  Uniform cell grid + one wavefront
  * per query on the MI355X instead of the reference's scan of the whole cloud per query.
  *   cloud_xyz [n_cloud][3], query_xyz [n_query][3] (z ignored when dim == 2), nbr [n_query][k] */
 int mmg_knn(int dim, int n_cloud, const double *cloud_xyz, const unsigned char *cloud_flag, long long n_query,

@@ -50,6 +50,7 @@ int g_graph = 0;
 thread_local bool g_capturing = false;  // inside hipStreamBeginCapture ... EndCapture of a cycle body
 unsigned long long g_state_gen = 1;     // bumped by everything a captured cycle body depends on besides its data
 int g_spin_bound = 1 << 22;        // mmg_set_option("debug_spin_bound", n): test hook, 0 makes every wait fail
+int g_debug_fail_graph = 0;        // mmg_set_option("debug_fail_graph", 1): test hook, the next graph instantiation "fails"
 long long g_sweep_fallbacks = 0;   // mmg_get_counter("sweep_fallbacks")
 
 int fail(int code, const std::string &msg)
@@ -890,14 +891,22 @@ int run_cycle_body(mmg_hierarchy *h)
             h->graph_failed = true;
             return run_cycle_body_plain(h);
         }
+        // sweep_epoch() restarts the levels' flag epochs while capturing; nothing runs during a capture, so if
+        // the graph cannot be built the flags on the device still hold the values of the sweeps launched so far
+        // (possibly far above the restarted epoch: un-captured sweeps after an earlier capture) -- the plain
+        // fallback run has to continue from the epochs the levels had BEFORE this capture
+        std::vector<unsigned> epoch_before;
+        for (mmg_level *l : h->lv) epoch_before.push_back(l->epoch);
         g_capturing = true;
         const int rc = run_cycle_body_plain(h);
         g_capturing = false;
         const hipError_t e = hipStreamEndCapture(g_stream, &graph);
-        if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (rc || e != hipSuccess || !graph || g_debug_fail_graph ||
+            hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0) != hipSuccess) {
             if (graph) (void)hipGraphDestroy(graph);
             h->gexec = nullptr;
             h->graph_failed = true;   // nothing ran: the body is issued directly from now on
+            for (size_t i = 0; i < h->lv.size(); ++i) h->lv[i]->epoch = epoch_before[i];
             (void)hipGetLastError();
             return rc ? rc : run_cycle_body_plain(h);
         }
@@ -1007,6 +1016,7 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "resid_lds") == 0) { g_resid_lds = value != 0; return MMG_OK; }
     if (std::strcmp(name, "waves_per_tile") == 0) { g_waves = value; return MMG_OK; }
     if (std::strcmp(name, "debug_spin_bound") == 0) { g_spin_bound = value < 0 ? (1 << 22) : value; return MMG_OK; }
+    if (std::strcmp(name, "debug_fail_graph") == 0) { g_debug_fail_graph = value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -1,5 +1,6 @@
 // fractionalStepGrid.cpp -- see fractionalStepGrid.hpp.
 #include "fractionalStepGrid.hpp"
+#include <cstring>
 #include "multigrid.h"
 
 #include <atomic>
@@ -130,11 +131,39 @@ void FractionalStepGrid::set_uv_bound()
         }
 }
 
+// point order, point count, polyDeg, rbfExp, neumannFlag_, dimension and every bcFlags_ entry (FNV-1a; never 0)
+unsigned long long FractionalStepGrid::op_cache_signature() const
+{
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&h](unsigned long long v) {
+        for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xffu; h *= 1099511628211ull; }
+    };
+    mix((unsigned long long)geom_version_);
+    mix((unsigned long long)points_.size());
+    mix((unsigned long long)properties_.polyDeg);
+    mix((unsigned long long)properties_.rbfExp);
+    mix((unsigned long long)(neumannFlag_ ? 1 : 0));
+    mix((unsigned long long)dim_);
+    for (int f : bcFlags_) { h ^= (unsigned)f & 0xffu; h *= 1099511628211ull; }
+    // coordinates: a strided sample of <= 256 points (direct edits of points_ that bypass apply_order)
+    const size_t np = points_.size(), step = std::max<size_t>(1, np / 256);
+    for (size_t i = 0; i < np; i += step) {
+        const double c[3] = {std::get<0>(points_[i]), std::get<1>(points_[i]), std::get<2>(points_[i])};
+        unsigned long long bits[3];
+        std::memcpy(bits, c, sizeof bits);
+        mix(bits[0]); mix(bits[1]); mix(bits[2]);
+    }
+    return h ? h : 1ull;
+}
+
 // fractionalStepGrid.cpp:60-100: one stencil row for EVERY point (which: 0 d/dx, 1 d/dy, 2 Laplacian, 3 d/dz)
 Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 {
     const int n = laplaceMatSize_;
-    if (op_cache_version_ != geom_version_) drop_op_cache();
+    // the cached operators of one device batch are only handed out while EVERYTHING their stencils depend on is
+    // unchanged (the reference rebuilds every operator from the current state, fractionalStepGrid.cpp:60-100)
+    const unsigned long long key = op_cache_signature();
+    if (op_cache_key_ != key) drop_op_cache();
     if (op_cache_[which]) {
         SparseRowMajor *m = op_cache_[which];
         op_cache_[which] = nullptr;
@@ -164,7 +193,7 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
                 m->adopt(std::move(outer), std::move(inner), std::move(val));
                 op_cache_[whichs[o]] = m;
             }
-            op_cache_version_ = geom_version_;
+            op_cache_key_ = key;
             SparseRowMajor *m = op_cache_[which];
             op_cache_[which] = nullptr;
             return m;
@@ -200,7 +229,7 @@ Grid::SparseRowMajor *FractionalStepGrid::build_op(int which)
 void FractionalStepGrid::drop_op_cache()
 {
     for (auto &m : op_cache_) { delete m; m = nullptr; }
-    op_cache_version_ = -1;
+    op_cache_key_ = 0;
 }
 
 void FractionalStepGrid::build_derivX_mat() { delete derivXMat_; derivXMat_ = build_op(0); }

@@ -51,7 +51,8 @@ protected:
     // D_x, D_y, (D_z,) velocity Laplacian of one device batch: ONE neighbour search and ONE factorisation per point
     // serve all of them; kept until each has been fetched (or the points are reordered)
     SparseRowMajor *op_cache_[4] = {nullptr, nullptr, nullptr, nullptr};
-    int op_cache_version_ = -1;
+    unsigned long long op_cache_key_ = 0;   // signature of the state the cached operators were built from (0: none)
+    unsigned long long op_cache_signature() const;
     void drop_op_cache();
     void fs_device();
     void push_uv();               // host u, v -> device when the host copy is newer

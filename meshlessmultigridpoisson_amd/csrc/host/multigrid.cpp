@@ -140,13 +140,19 @@ void Multigrid::ensure_device()
     for (size_t i = 0; i + 1 < nl; ++i) devP_[i] = mk(prolongMatrices_[i]);
     std::vector<mmg_level *> lv;
     for (auto &g : grids_) lv.push_back(g.second->device());
-    dev_check(mmg_hierarchy_create(&devH_, lv.data(), (int)nl, devR_.data(), devP_.data(), fracStep_ ? 1 : 0), "mmg_hierarchy_create");
-    if (correctionDamping_ != 1.0)
-        dev_check(mmg_hierarchy_set_correction_damping(devH_, correctionDamping_), "mmg_hierarchy_set_correction_damping");
+    mmg_hierarchy *hh = nullptr;
+    dev_check(mmg_hierarchy_create(&hh, lv.data(), (int)nl, devR_.data(), devP_.data(), fracStep_ ? 1 : 0), "mmg_hierarchy_create");
+    if (correctionDamping_ != 1.0 && mmg_hierarchy_set_correction_damping(hh, correctionDamping_) != MMG_OK) {
+        mmg_hierarchy_destroy(hh);  // devH_ is only published once it is completely configured
+        dev_check(MMG_ERR_INVALID, "mmg_hierarchy_set_correction_damping");
+    }
+    devH_ = hh;
 }
 
 void Multigrid::setCorrectionDamping(double theta)
 {
+    if (!(theta > 0.0 && theta <= 1.0))  // validated BEFORE it is stored: a bad value must not survive in the member
+        throw std::invalid_argument("Multigrid::setCorrectionDamping: theta must lie in (0, 1]");
     correctionDamping_ = theta;
     if (devH_) dev_check(mmg_hierarchy_set_correction_damping(devH_, theta), "mmg_hierarchy_set_correction_damping");
 }

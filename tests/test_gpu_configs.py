@@ -238,6 +238,37 @@ def test_vcycle_body_as_hip_graph_changes_no_bit():
         _capi.set_option("vcycle_graph", 0)
 
 
+def test_failed_graph_capture_continues_from_the_flag_epochs_before_it():
+    """A re-capture that cannot be instantiated (mmg_set_option("debug_fail_graph", 1) forces the branch) falls back
+    to plain launches.  The capture had restarted the levels' flag epochs although nothing ran; the flags on the
+    device still hold the (large) values of the un-captured sweeps issued after the FIRST capture -- the fallback must
+    continue from the epochs before the failed capture, or its dependency waits pass at once and the sweeps race.
+    Same history as a hierarchy that never used graphs, bit for bit."""
+    from meshlessmultigridpoisson_amd import _capi
+    case = H.load_case("neumann_2level")
+
+    def run(use_graph):
+        _capi.set_option("vcycle_graph", int(use_graph))
+        h = H.device_hierarchy(case)
+        r = [h.vcycle() for _ in range(3)]            # plain run, capture + replay, replay
+        for lv in h.levels:
+            lv.sweeps(3)                               # un-captured launches: flags far above the restarted epoch
+        if use_graph:
+            _capi.set_option("debug_fail_graph", 1)   # (any option change also invalidates the captured graph)
+        r += [h.vcycle() for _ in range(3)]           # re-capture fails -> plain body, for good
+        _capi.set_option("debug_fail_graph", 0)
+        r += [h.vcycle() for _ in range(2)]
+        return h, r
+
+    try:
+        plain, rp = run(False)
+        dh, rg = run(True)
+        assert rg == rp
+        assert np.array_equal(dh.levels[-1].get_x(), plain.levels[-1].get_x())
+    finally:
+        _capi.set_option("debug_fail_graph", 0)
+        _capi.set_option("vcycle_graph", 0)
+
 
 @pytest.mark.parametrize("dim,sides,degs", [(2, [25, 49], [5, 5]), (2, [25, 49], [6, 6]), (2, [31, 61, 121], [3, 4, 5]),
                                             (3, [9, 17], [2, 2]), (3, [11, 21], [4, 4])])

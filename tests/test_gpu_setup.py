@@ -317,3 +317,41 @@ def test_knn_edge_cases(host):
         _capi.knn(2, cloud, cloud[:4], 257)
     dup = np.concatenate([cloud[:50], cloud[:50], cloud[50:300]])       # every one of the first 50 points twice
     assert np.array_equal(_capi.knn(2, dup, dup[:100], 9), _brute_knn(dup, dup[:100], 9, 2))
+
+
+def _reference_knn(cloud, cloud_flag, q, q_flag, k):
+    """grid.cpp:216-260 restated literally for one query: distances to every point, samePoint = the LAST index at
+    distance 0 (:219-226), a max-heap of k candidates in which a flagged candidate is admitted only if it is
+    samePoint (:236,244); returns the k smallest (distance, index) pairs in order."""
+    d = np.sqrt((cloud[:, 0] - q[0]) ** 2 + (cloud[:, 1] - q[1]) ** 2)
+    zero = np.flatnonzero(d == 0.0)
+    same = int(zero[-1]) if len(zero) else -1
+    cand = [(d[i], i) for i in range(len(cloud)) if i == same or not (q_flag and cloud_flag[i] != 0)]
+    cand.sort()
+    return [i for _d, i in cand[:k]]
+
+
+def test_knn_flagged_query_rule_on_coincident_boundary_points(host):
+    """the reference exempts ONE zero-distance candidate from the boundary exclusion (samePoint,
+    the last index at distance 0); mmg_knn keeps every flagged candidate at distance 0 (documented in mmgp.h).  On a
+    cloud without coincident points the two rules are the same lists; with a boundary point stored twice the device
+    list is the reference's plus the extra coincident copy (and one far neighbour fewer) -- nothing else differs."""
+    from meshlessmultigridpoisson_amd import _capi
+    pts = host.quasi_uniform_square_cloud(12)
+    flag = ((pts[:, 0] == 0) | (pts[:, 0] == 1) | (pts[:, 1] == 0) | (pts[:, 1] == 1)).astype(np.uint8)
+    k = 25
+    got = _capi.knn(2, pts, pts, k, flag, flag)
+    for i in range(len(pts)):
+        assert list(got[i]) == _reference_knn(pts, flag, pts[i], flag[i], k), i
+    b = int(np.flatnonzero(flag)[5])
+    dup = np.concatenate([pts, pts[b:b + 1]])           # boundary point b stored a second time (index n)
+    dflag = np.append(flag, 1).astype(np.uint8)
+    got = _capi.knn(2, dup, dup, k, dflag, dflag)
+    n = len(pts)
+    for i in range(len(dup)):
+        ref = _reference_knn(dup, dflag, dup[i], dflag[i], k)
+        if i in (b, n):                                  # the coincident pair: both copies at distance 0 are kept
+            assert list(got[i][:2]) == [b, n] and ref[0] == n
+            assert list(got[i][2:]) == ref[1:k - 1]
+        else:
+            assert list(got[i]) == ref, i
