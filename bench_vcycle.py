@@ -28,7 +28,13 @@ def main():
     ap.add_argument("--lds-resident", type=int, default=1, help="0: plain per-phase kernel on small levels (A/B)")
     ap.add_argument("--graph", type=int, default=1, help="0: issue every launch of the cycle body directly (A/B of the HIP graph)")
     ap.add_argument("--waves", type=int, default=0, help="waves_per_tile option: 0 automatic, 1 packed stream everywhere (A/B)")
-    ap.add_argument("--point-colouring", type=int, default=1, help="0: greedy point colours in tile order (A/B)")
+    ap.add_argument("--point-colouring", type=int, default=-1, help="-1 automatic (2-D: 2, 3-D: 1); 0 / 1: point colours inside the tiles; 2: lexicographic SWEEP order inside the tiles")
+    ap.add_argument("--tile-order", type=int, default=0, help="1: tiles in lexicographic sweep order instead of tile colours")
+    ap.add_argument("--tile", type=int, default=0, help="points per tile (0: automatic)")
+    ap.add_argument("--cloud", default="jitter", choices=["jitter", "gmsh"], help="gmsh: quasi_uniform_square_cloud (2-D only)")
+    ap.add_argument("--neumann", type=int, default=0)
+    ap.add_argument("--ordering", default="mc", choices=["mc", "rcm"], help="rcm: the reference's rcm_order_points")
+    ap.add_argument("--sides", type=str, default="", help="explicit comma-separated sides, coarse to fine (overrides --nside/--levels)")
     ap.add_argument("--per-level", type=str, default="", help="write a per-level table (sweep, residual: us, %% of 8 TB/s) to this markdown file")
     a = ap.parse_args()
     from meshlessmultigridpoisson_amd import _capi, _host
@@ -37,24 +43,34 @@ def main():
     _capi.set_option("vcycle_graph", a.graph)
     _capi.set_option("waves_per_tile", a.waves)
     _host.set_option("point_colouring", a.point_colouring)
+    _host.set_option("tile_order", a.tile_order)
     t0 = time.perf_counter()
     sides = [max(9, a.nside // (2 ** (a.levels - 1 - l))) for l in range(a.levels)]
+    if a.sides:
+        sides = [int(v) for v in a.sides.split(",")]
+        a.levels = len(sides)
     if a.dim == 3:
-        clouds = [_host.box_cloud(n, 3, seed=12345 + i) for i, n in enumerate(sides)]
+        clouds = [_host.box_cloud(n, 3, seed=12345 + i, edges=not a.neumann) for i, n in enumerate(sides)]
+    elif a.cloud == "gmsh":
+        clouds = [_host.quasi_uniform_square_cloud(n) for n in sides]
     else:
         clouds = [_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides)]
     polys = [3] * (a.levels - 1) + [a.polydeg]
-    mg = _host.Multigrid(clouds, polys, dim=a.dim, neumann=False, ordering=_host.ORDER_MC, tile_points=0,
+    mg = _host.Multigrid(clouds, polys, dim=a.dim, neumann=bool(a.neumann),
+                         ordering=_host.ORDER_MC if a.ordering == "mc" else _host.ORDER_RCM, tile_points=a.tile,
                          omega=a.omega, iters=a.iters)
     t_setup = time.perf_counter() - t0
     res, ms = mg.vcycles(3)  # warm-up, creates the device hierarchy
     t0 = time.perf_counter()
     res, ms = mg.vcycles(a.cycles)
     wall = time.perf_counter() - t0
-    out = {"workload": f"{a.dim}-D {sides[-1]}^{a.dim} = {sides[-1] ** a.dim} points, {a.levels} levels {sides}, polyDeg {polys}, omega {a.omega}, iters {a.iters}",
+    n_fine = mg.grid(mg.nlevels - 1).sizes()["n"]
+    out = {"workload": f"{a.dim}-D {a.cloud} cloud, {n_fine} points, {a.levels} levels {sides}, polyDeg {polys}, omega {a.omega}, iters {a.iters}, "
+                       f"{'Neumann' if a.neumann else 'Dirichlet'}, ordering {a.ordering} (point order {a.point_colouring}, tile order {a.tile_order}, tile {a.tile})",
+           "contraction_per_cycle": float((res[-1] / res[len(res) // 2]) ** (1.0 / max(1, len(res) - 1 - len(res) // 2))) if res[len(res) // 2] > 0 else None,
            "setup_seconds": round(t_setup, 1), "cycles": a.cycles, "device_ms_per_vcycle": ms / a.cycles,
            "wall_ms_per_vcycle": wall / a.cycles * 1e3, "residuals": [float(r) for r in mg.residuals[:8]], "residual_before_last_cycle": float(res[-1]),
-           "fine_points_per_s_per_vcycle": sides[-1] ** a.dim / (ms / a.cycles * 1e-3)}
+           "fine_points_per_s_per_vcycle": n_fine / (ms / a.cycles * 1e-3)}
     if a.per_level:
         import numpy as np
         lines = [f"## {out['workload']}", "",

@@ -197,6 +197,9 @@ int mmg_level_time_phases(mmg_level *lv, int nsweeps, float *kernel_ms, int *lau
 int mmg_comm_get_unique_id(char *id128);   /* 128 bytes; the caller broadcasts rank 0's */
 int mmg_comm_init(int rank, int nranks, const char *id128);
 int mmg_comm_finalize(void);
+/* Size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) -- evidence that
+ * the ranks of a run really share ONE communicator; MMG_ERR_COMM before mmg_comm_init. */
+int mmg_comm_info(int *nranks, int *rank);
 /* Ghost refresh schedule of a distributed level (collective: every rank calls it after
  * mmg_level_set_exchange).  per_phase = 0 (default): once per sweep -- block-hybrid Gauss-Seidel,
  * foreign columns see the previous sweep.  per_phase = 1: before EVERY phase of a sweep -- the
@@ -217,6 +220,11 @@ int mmg_level_point_phases(mmg_level *lv, int *phase, int n);
 int mmg_level_set_exchange(mmg_level *lv, int n_owned_points, int n_nbr, const int *nbr_rank,
                            const int *send_ptr, const int *send_idx, const int *recv_ptr);
 int mmg_level_exchange(mmg_level *lv);
+/* What one ghost refresh of this level moves: neighbours, values sent, values received (8 bytes each). */
+int mmg_level_exchange_info(const mmg_level *lv, int *n_neighbours, long long *send_values, long long *recv_values);
+/* `reps` ghost refreshes (pack kernel + grouped ncclSend / ncclRecv), each bracketed by a hipEvent pair on the
+ * library's stream: ms_out[reps].  Collective -- every rank of the communicator calls it with the same reps. */
+int mmg_level_time_exchange(mmg_level *lv, int reps, float *ms_out);
 
 /* ---- transfers == restrictionMatrices_/prolongMatrices_ ------------------- */
 /* The reference stores them column-major (multigrid.h:8-9): pass

@@ -57,6 +57,7 @@ SYMBOLS = [
     "mmg_hierarchy_set_correction_damping",
     "mmg_host_threads",
     "mmg_rbf_stencils",
+    "mmg_comm_info", "mmg_level_exchange_info", "mmg_level_time_exchange",
 ]
 
 _lib = None
@@ -92,6 +93,9 @@ def lib():
         L.mmg_level_time_sweeps.argtypes = [vp, C.c_int, C.c_int, _fp]
         L.mmg_level_time_residual.argtypes = [vp, C.c_int, _fp]
         L.mmg_level_time_phases.argtypes = [vp, C.c_int, _fp, _ip]
+        L.mmg_level_time_exchange.argtypes = [vp, C.c_int, _fp]
+        L.mmg_level_exchange_info.argtypes = [vp, _ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        L.mmg_comm_info.argtypes = [_ip, _ip]
         L.mmg_transfer_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _ip, _ip, _dp, C.c_int]
         L.mmg_transfer_destroy.argtypes = [vp]
         L.mmg_transfer_destroy.restype = None
@@ -153,6 +157,13 @@ def comm_init(rank, nranks, id128):
 
 def comm_finalize():
     check(lib().mmg_comm_finalize())
+
+
+def comm_info():
+    """(ranks, rank) read back from RCCL (ncclCommCount / ncclCommUserRank)"""
+    n, r = C.c_int(0), C.c_int(-1)
+    check(lib().mmg_comm_info(C.byref(n), C.byref(r)))
+    return n.value, r.value
 
 
 def set_option(name, value):
@@ -323,6 +334,18 @@ class Level:
 
     def exchange(self):
         check(lib().mmg_level_exchange(self.h))
+
+    def exchange_info(self):
+        """(neighbours, values sent, values received) of one ghost refresh"""
+        k, ns, nr = C.c_int(0), C.c_longlong(0), C.c_longlong(0)
+        check(lib().mmg_level_exchange_info(self.h, C.byref(k), C.byref(ns), C.byref(nr)))
+        return k.value, ns.value, nr.value
+
+    def time_exchange(self, reps):
+        """device ms of `reps` ghost refreshes (collective)"""
+        ms = (C.c_float * reps)()
+        check(lib().mmg_level_time_exchange(self.h, int(reps), ms))
+        return [float(v) for v in ms]
 
     def time_phases(self, nsweeps):
         ms, cnt = C.c_float(0), C.c_int(0)

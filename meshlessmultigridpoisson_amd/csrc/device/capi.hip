@@ -99,6 +99,8 @@ struct Rccl {
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
 };
@@ -126,6 +128,8 @@ int rccl_load()
     RSYM(AllReduce, "ncclAllReduce")
     RSYM(AllGather, "ncclAllGather")
     RSYM(GetErrorString, "ncclGetErrorString")
+    RSYM(CommCount, "ncclCommCount")
+    RSYM(CommUserRank, "ncclCommUserRank")
 #undef RSYM
     return MMG_OK;
 }
@@ -1514,6 +1518,47 @@ int mmg_comm_init(int rank, int nranks, const char *id128)
     g_rccl.rank = rank;
     g_rccl.nranks = nranks;
     return MMG_OK;
+}
+
+int mmg_comm_info(int *nranks, int *rank)
+{
+    if (!g_rccl.comm) return fail(MMG_ERR_COMM, "mmg_comm_init has not been called");
+    int n = 0, r = -1;
+    NCCLC(g_rccl.CommCount(g_rccl.comm, &n));      // read back from RCCL, not the values mmg_comm_init was given
+    NCCLC(g_rccl.CommUserRank(g_rccl.comm, &r));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return MMG_OK;
+}
+
+int mmg_level_exchange_info(const mmg_level *lv, int *n_neighbours, long long *send_values, long long *recv_values)
+{
+    if (!lv) return fail(MMG_ERR_INVALID, "null level");
+    const size_t k = lv->nbr.size();
+    if (n_neighbours) *n_neighbours = (int)k;
+    if (send_values) *send_values = k ? lv->send_ptr[k] : 0;
+    if (recv_values) *recv_values = k ? lv->recv_ptr[k] : 0;
+    return MMG_OK;
+}
+
+int mmg_level_time_exchange(mmg_level *lv, int reps, float *ms_out)
+{
+    if (!lv || !ms_out || reps < 1) return fail(MMG_ERR_INVALID, "bad argument");
+    if (int src_ = settle(lv)) return src_;
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    int rc = MMG_OK;
+    for (int r = 0; r < reps && !rc; ++r) {     // collective: every rank calls it with the same reps
+        HIPC(hipEventRecord(e0, g_stream));
+        rc = exchange(lv);
+        HIPC(hipEventRecord(e1, g_stream));
+        HIPC(hipEventSynchronize(e1));
+        HIPC(hipEventElapsedTime(&ms_out[r], e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int mmg_comm_finalize(void)

@@ -75,6 +75,7 @@ Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties pro
     diags = VectorXd((size_t)A_size);
     device_setup_ = default_device_setup;
     point_colouring_ = default_point_colouring;
+    tile_order_ = default_tile_order;
     if (default_mult_row > 0.0) multRow_ = default_mult_row;
 }
 
@@ -344,7 +345,8 @@ double Grid::multiplier_row_value() const
 
 double Grid::default_mult_row = 0.0;
 int Grid::default_device_setup = -1;
-int Grid::default_point_colouring = 1;
+int Grid::default_point_colouring = -1;
+int Grid::default_tile_order = 0;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
                             const vector<int> &ops, mmgh::RawVec<int> &nbr, mmgh::RawVec<double> &w, bool by_column)

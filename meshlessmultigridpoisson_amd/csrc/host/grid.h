@@ -62,8 +62,11 @@ public:
     double multiplier_row_value() const;
     static double default_mult_row;  // value new grids start with (mmgh_set_option "multiplier_row_ppm", millionths; 0 = automatic)
     int geom_version_ = 0;       // bumped by apply_order: caches keyed on the point order compare it
-    int point_colouring_ = 1;    // mc_order_points, points of a tile: 0 greedy in tile order, 1 smallest-last + iterated greedy
-    static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring")
+    int point_colouring_ = -1;   // mc_order_points, points of a tile: -1 automatic (2-D: 2, 3-D: 1), 0 greedy colours in tile order,
+                                 // 1 smallest-last + iterated greedy colours, 2 lexicographic SWEEP order (no colour classes)
+    static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring"); 2: lexicographic SWEEP order inside the tiles
+    int tile_order_ = 0;         // mc_order_points, order of the tiles: 0 by tile colour (4 / 8 phases), 1 lexicographic sweep over the tiles
+    static int default_tile_order;       // mmgh_set_option "tile_order"
     int setup_threads_ = 0;      // 0 = hardware concurrency
     // Dense stencil solves of the setup (laplaceWeights / pointInterpWeights / deriv*_weights):
     // -1 automatic (batched on the MI355X through mmg_rbf_weights when a device is present and

@@ -331,6 +331,10 @@ void Grid::mc_order_points(int tile_points)
     // ---- 3. point colours inside each tile --------------------------------------------
     st.reset(new mmgh::SetupTimer("mc_order_points: point colours"));
     vector<int> pcol((size_t)n, 0), tile_ncol((size_t)nt, 0);
+    // automatic (-1): 2-D clouds get the sweep order (the reference's 2-D parameter sets -- omega 1.4, fine polyDeg
+    // 4-6 -- diverge under colour classes and contract under a sweep); 3-D clouds keep the colour
+    // classes (K = 50 Dirichlet hierarchies contract alike under both, the sweep order costs 4x there)
+    const int point_order = point_colouring_ >= 0 ? point_colouring_ : (dim_ >= 3 ? 1 : 2);
     par_for(nt, nth, [&](int t) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
         vector<vector<int>> ladj((size_t)m);
@@ -365,7 +369,23 @@ void Grid::mc_order_points(int tile_points)
             }
             return used;
         };
-        if (point_colouring_ == 0 || n_t > 3000000) {  // plain greedy in tile order (round 1; bandwidth-bound levels: the chain is hidden)
+        if (point_order == 2) {
+            // SWEEP order inside the tile: the points keep a lexicographic (z, y, x) order instead of colour classes.
+            // Over-relaxed point SOR (the reference's omega = 1.4) is a good smoother only in a directional sweep
+            // such as the reference's RCM order (grid.cpp:713-776); with colour classes the reference's V-cycle
+            // contracts worse or diverges (193^2 Dirichlet, polyDeg 4: RCM / lexicographic 0.44
+            // per cycle, multicolour x 1.37).  The price: the dependency chain of a tile is ~5 sqrt(tile points)
+            // levels instead of ~20 colours.
+            vector<int> ord((size_t)m);
+            std::iota(ord.begin(), ord.end(), 0);
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+                const Point &px = points_[(size_t)idx[(size_t)(b + x)]], &py = points_[(size_t)idx[(size_t)(b + y)]];
+                if (dim_ >= 3 && std::get<2>(px) != std::get<2>(py)) return std::get<2>(px) < std::get<2>(py);
+                if (std::get<1>(px) != std::get<1>(py)) return std::get<1>(px) < std::get<1>(py);
+                return std::get<0>(px) < std::get<0>(py);
+            });
+            for (int r = 0; r < m; ++r) col[(size_t)ord[(size_t)r]] = r;
+        } else if (point_order == 0 || n_t > 3000000) {  // plain greedy in tile order (round 1; bandwidth-bound levels: the chain is hidden)
             for (int k = 0; k < m; ++k)
                 if (relaxed[(size_t)k]) order.push_back(k);
             greedy(order);
@@ -425,14 +445,18 @@ void Grid::mc_order_points(int tile_points)
         long long sum = 0;
         int mx = 0;
         for (int c : tile_ncol) { sum += c; mx = std::max(mx, c); }
-        std::fprintf(stderr, "[mc_order_points] point colours per tile: mean %.1f, max %d (colouring %d)\n", (double)sum / nt, mx, point_colouring_);
+        std::fprintf(stderr, "[mc_order_points] point colours per tile: mean %.1f, max %d (colouring %d)\n", (double)sum / nt, mx, point_order);
     }
 
     // ---- storage order --------------------------------------------------------------------
     st.reset(new mmgh::SetupTimer("mc_order_points: storage order"));
     vector<int> torder((size_t)nt);
     std::iota(torder.begin(), torder.end(), 0);
-    std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
+    if (tile_order_ == 0)
+        std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
+    else
+        std::fill(tcol.begin(), tcol.end(), -1);   // tiles stay in their lexicographic (z, y, x) box order: a sweep over
+                                                   // tiles; libmmgp derives the (wavefront) phases from the couplings
     vector<int> tptr(1, 0);
     vector<int> tcolour;
     for (int t : torder) {
@@ -457,4 +481,5 @@ void Grid::mc_order_points(int tile_points)
     apply_order(order);
     tile_ptr_ = tptr;
     tile_colour_ = tcolour;
+    if (tile_order_ != 0) tile_colour_.clear();   // no phase hints: they follow from the order
 }

@@ -250,6 +250,17 @@ def emu_transfer_apply(shape, colptr, rowidx, val, x, add_to=None, L=4):
     return y
 
 
+def rho_evaluation_noise(lv):
+    """First-order bound of the rounding error of rho = ||b - A x||_1 / ||b||_1 evaluated in ANY association order:
+    eps * || |A||x| + |b| ||_1 / ||b||_1 for the oracle Level `lv` in its current state.  Two correct evaluations
+    (the CPU's sequential row sums, the GPU's lane-parallel ones) may differ by this much whatever rho is; it grows
+    with 1/h^2 and with the weight size of high-degree stencils (2e-13 on the 600-point fixtures, 4e-12 on a
+    10874-point polyDeg-6 Neumann level)."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.abs(lv.val), lv.col, lv.rowptr), shape=(lv.a_size, lv.a_size))
+    return float(np.finfo(np.float64).eps * ((A @ np.abs(lv.x)).sum() + np.abs(lv.b).sum()) / np.abs(lv.b).sum())
+
+
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

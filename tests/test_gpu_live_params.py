@@ -6,9 +6,11 @@
 points) are not in the repository; the clouds here are the Gmsh-like `quasi_uniform_*_cloud` (185 / 704 / 2750 /
 10874 points) on which the reference's arithmetic contracts (tests/test_live_params.py).
 
-Tolerance, as everywhere: |rho_gpu - rho_cpu| <= 1e-10 * rho_cpu + 2e-13 per V-cycle (1e-10 relative is
-BASELINE.json's north_star; the absolute floor is the fp64 evaluation noise of rho itself); exact-arithmetic mode
-bitwise.  Every call goes through the C-ABI (libmmgp.so); the oracle is the checker.
+Tolerance: |rho_gpu - rho_cpu| <= 1e-10 * rho_cpu + noise per V-cycle.  1e-10 relative is BASELINE.json's north_star;
+`noise` is the fp64 evaluation noise of rho = ||b - A x||_1 / ||b||_1 itself, eps * || |A||x| + |b| ||_1 / ||b||_1
+(helpers.rho_evaluation_noise: what two correct evaluations in different association orders may differ by) and at
+least the 2e-13 used on the small fixtures -- 4e-12 on the 10874-point polyDeg-6 level, where a relative 1e-10 alone
+would be demanded of differences below the rounding of a single evaluation.  Exact-arithmetic mode: bitwise.  Every call goes through the C-ABI (libmmgp.so); the oracle is the checker.
 """
 import numpy as np
 import pytest
@@ -31,7 +33,7 @@ def _follow(mg, om, ncycles):
     hist = []
     for k in range(ncycles):
         ro, rd = om.vcycle(), mg.vcycle()
-        assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+        assert abs(rd - ro) <= 1e-10 * ro + max(FLOOR, H.rho_evaluation_noise(om.levels[-1])), (k, rd, ro)
         hist.append(rd)
     return hist
 
