@@ -77,7 +77,11 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = --nside^dim points per rank; strong = one --total-nside^dim cloud shared by all ranks")
     ap.add_argument("--total-nside", type=int, default=342, help="--scaling strong: points per axis of the whole cloud")
-    ap.add_argument("--no-vcycle", action="store_true", help="skip the two whole-V-cycle legs (N=1)")
+    ap.add_argument("--no-vcycle", action="store_true", help="skip the whole-V-cycle legs")
+    ap.add_argument("--dd-vcycle-nside", type=int, default=128,
+                    help="N>1: points per axis of the ONE cloud of the distributed V-cycle leg (every rank builds the global hierarchy)")
+    ap.add_argument("--replicate-below", type=int, default=70000,
+                    help="N>1 V-cycle leg: levels with fewer points are kept complete on every rank")
     ap.add_argument("--no-fracstep", action="store_true", help="skip the 3-D fractional-step leg (N=1)")
     ap.add_argument("--vcycle-cycles", type=int, default=10)
     ap.add_argument("--verify", type=int, default=0,
@@ -250,6 +254,41 @@ def fracstep_leg(steps=2, coarse_iters=60):
             "fs_residual": float(recs[-1][2]), "setup_seconds": round(t_setup, 1)}
 
 
+def distributed_vcycle_leg(a, rank, world, dist):
+    """Whole V-cycles over `world` GPUs: every rank builds the SAME global hierarchy
+    (--dd-vcycle-nside^3 points, 4 levels), keeps its x-slab of every level with at least --replicate-below points and
+    a complete copy of the smaller ones (Multigrid::extract_subdomain), registers the exchange lists it worked out
+    without communication (Multigrid::setup_exchange) and runs Multigrid::vCycles: ghost refresh before every sweep
+    / residual / transfer on the decomposed levels, one ncclAllGather per cycle in front of the first replicated
+    level, no collective on the replicated ones.  Time = max over ranks of the device time per cycle."""
+    from meshlessmultigridpoisson_amd import _host
+    t0 = time.perf_counter()
+    ns = a.dd_vcycle_nside
+    sides = [max(9, ns // (2 ** (3 - l))) for l in range(4)]
+    clouds = [_host.box_cloud(n, 3, seed=777 + i) for i, n in enumerate(sides)]
+    _host.set_option("device_setup", 1)
+    mg = _host.Multigrid(clouds, [a.polydeg] * 4, dim=3, neumann=False, ordering=_host.ORDER_MC, tile_points=0)
+    sub = mg.extract_subdomain(world, rank, replicate_below=a.replicate_below)
+    del mg
+    sub.setup_exchange_native(exact=False)
+    t_setup = time.perf_counter() - t0
+    sub.vcycles(2)
+    res, ms = sub.vcycles(a.vcycle_cycles)
+    per = ms / a.vcycle_cycles
+    if dist is not None:
+        import torch
+        t = torch.tensor([per, t_setup], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per, t_setup = float(t[0].item()), float(t[1].item())
+    return {"workload": f"3-D {ns}^3 = {ns ** 3} points in ONE cloud, 4 levels {sides}, RBF-FD degree {a.polydeg}, Dirichlet, omega 1.4, "
+                        f"V(5,5), x-slabs over {world} GPUs, levels below {a.replicate_below} points replicated",
+            "levels": sides, "replicated": [bool(sub.grid(l).is_replicated()) for l in range(sub.nlevels)],
+            "ms_per_vcycle_max_over_ranks": per, "fine_Mpoints_per_s": ns ** 3 / (per * 1e-3) / 1e6,
+            "setup_seconds_max_over_ranks": round(t_setup, 1),
+            "residual_history": [float(r) for r in res[:4]],
+            "contraction_per_cycle": float((res[-1] / res[0]) ** (1.0 / max(1, len(res) - 1))) if res[0] > 0 else None}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` outside torch.distributed.run: start it (one rank per GPU, 127.0.0.1
     rendezvous) as a CHILD process -- nothing in this process has touched the GPU yet -- and relay its one
@@ -377,12 +416,27 @@ def main():
     t_dev = time.perf_counter()
     lv = _capi.Level.borrow(grid.device_level(), sz["n"], sz["a_size"])
     t_dev = time.perf_counter() - t_dev
+    multi = None
     if dd:
         lv.set_exchange(n_owned, nbr, sp, si, rp)
         if a.exchange == "phase":
             lv.set_exchange_mode(1)
     info = lv.info()
     t_setup = time.perf_counter() - t_setup
+    if dd:
+        # evidence for the N > 1 line: communicator size read back from RCCL, what one ghost refresh moves and costs
+        # (HIP events around pack + grouped ncclSend / ncclRecv on the library's stream; collective), setup per rank
+        rccl_ranks, rccl_rank = _capi.comm_info()
+        n_nbr, n_send, n_recv = lv.exchange_info()
+        xms = lv.time_exchange(12)[2:]
+        per_rank = all_gather_object({"rank": rank, "rccl_rank": rccl_rank, "setup_seconds": round(t_setup, 1),
+                                      "neighbours": n_nbr, "ghost_values_sent": n_send, "ghost_values_received": n_recv,
+                                      "exchange_us_median": float(np.median(xms)) * 1e3, "points": int(n_owned)})
+        multi = {"rccl_ranks": rccl_ranks, "world_size": world, "per_rank": per_rank,
+                 "exchange_us_per_refresh_max_over_ranks": max(r["exchange_us_median"] for r in per_rank),
+                 "ghost_bytes_per_refresh_per_rank_max": 8 * max(r["ghost_values_received"] for r in per_rank),
+                 "setup_seconds_max_over_ranks": max(r["setup_seconds"] for r in per_rank),
+                 "refreshes_per_sweep": 1 if a.exchange == "sweep" else info["n_phases"]}
     # setup_seconds: the bench level (cloud -> ordering -> operator -> packed device layout); the coarser grids and
     # the transfer matrices of the V-cycle leg's hierarchy are reported apart
     t_hier = 0.0
@@ -450,6 +504,13 @@ def main():
     kern_ms, launches = lv.time_phases(sweeps_timed)
     alg_bytes = interior * b_sor(stencil) * sweeps_timed
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # the same kernel as the V-cycle launches it: `iters` = 5 sweeps per smoothing call (multigrid.cpp:79,108), so the
+    # ramp-up and the tail of the dependency-driven launch are paid every 5 sweeps instead of every 16
+    vc_sweeps = 5
+    kern_ms5, launches5 = lv.time_phases(vc_sweeps)
+    kern_ms5b, _l5 = lv.time_phases(vc_sweeps)
+    kern_ms5 = min(kern_ms5, kern_ms5b)
+    achieved5 = interior * b_sor(stencil) * vc_sweeps / (kern_ms5 * 1e-3) / 1e9
 
     # residual SpMV on the same level (Grid::residual, grid.cpp:147-151, + the two L1 norms of
     # Multigrid::residual): r = b - A x over the same packed stream, HIP events on the library's stream
@@ -479,24 +540,44 @@ def main():
         pass
 
     if not dd and not a.no_vcycle and a.operator == "rbf":
+        # BASELINE configs[1]: 2-D ~1e6 points, on the reference-shaped (Gmsh-like) cloud, the reference's own parameters
+        # (omega 1.4, 5 sweeps, fine polyDeg 4, testing_functions.cpp:372-380).  Three legs:
+        #   [0] 5 levels as configs[1] states, sweep point order: contracts slowly (the coarsest grid of 59^2 is only
+        #       smoothed, 10 sweeps);  [1] the same cloud coarsened down to ~244 points like the reference's mesh series
+        #       (170 -> 600 -> 2.5k -> 10k, x4 per level): 7 levels, contracts 0.6 per cycle;  [2] 5 levels with colour
+        #       classes inside the tiles (round 2's order): the fastest schedule, but the cycle DIVERGES at omega 1.4.
+        legs2 = [("5 levels as BASELINE configs[1] states", [59, 117, 233, 466, 931], -1),
+                 ("7 levels: coarsened like the reference's mesh series down to 244 points", [15, 30, 59, 117, 233, 466, 931], -1),
+                 ("5 levels, COLOUR classes inside the tiles (round-2 order; NOT a converging cycle at omega 1.4)",
+                  [59, 117, 233, 466, 931], 1)]
+        for li, (what, sides2, pcol) in enumerate(legs2):
+            try:
+                polys2 = [3] * (len(sides2) - 1) + [4]
+                t2 = time.perf_counter()
+                _host.set_option("point_colouring", pcol)
+                try:
+                    mg2 = _host.Multigrid([_host.quasi_uniform_square_cloud(n) for n in sides2], polys2, dim=2,
+                                          neumann=False, ordering=_host.ORDER_MC, tile_points=0, omega=1.4)
+                finally:
+                    _host.set_option("point_colouring", -1)
+                leg = vcycle_leg(mg2, f"BASELINE configs[1]: 2-D Gmsh-like cloud of {mg2.grid(len(sides2) - 1).sizes()['n']} points "
+                                      f"(quasi_uniform_square_cloud({sides2[-1]})), {what}; RBF-FD degree 4 (K=37) on the finest "
+                                      f"level, 3 (K=25) below, Dirichlet, omega 1.4, V(5,5) -- the reference's parameters; point "
+                                      f"order inside the tiles: {'lexicographic sweep' if pcol != 1 else 'colour classes'}",
+                                 2, sides2, polys2, 2 * a.vcycle_cycles, 5, oracle_cycles=0 if (a.no_cpu or li != 0) else 2)
+                leg["point_order"] = "sweep" if pcol != 1 else "colour"
+                leg["converging"] = bool(leg["contraction_per_cycle_timed_cycles"] is not None and leg["contraction_per_cycle_timed_cycles"] < 1.0)
+                leg["setup_seconds"] = round(time.perf_counter() - t2, 1)
+                vcycles.insert(li, leg)
+                del mg2
+            except Exception as e:  # noqa: BLE001
+                vcycles.insert(li, {"workload": "BASELINE configs[1]: " + what, "error": str(e)})
+
+    if dd and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:
         try:
-            sides2 = [62, 125, 250, 500, 1000]
-            polys2 = [3, 3, 3, 3, 4]
-            t2 = time.perf_counter()
-            # omega 1.0: with the reference's default 1.4 this hierarchy's V-cycle DIVERGES from the 500^2 level on
-            # (x 1.8 per cycle; 1.2: x 1.19; 1.0 contracts, 0.99 per cycle) -- in the CPU oracle exactly as on the
-            # device.  The time per cycle does not depend on omega.
-            mg2 = _host.Multigrid([_host.square_cloud(n, seed=12345 + i) for i, n in enumerate(sides2)], polys2, dim=2,
-                                  neumann=False, ordering=_host.ORDER_MC, tile_points=0, omega=1.0)
-            leg = vcycle_leg(mg2, "BASELINE configs[1]: 2-D 1000^2 = 1e6 points, 5 levels, RBF-FD degree 4 (K=37) on the "
-                                  "finest level, 3 (K=25) below, Dirichlet, omega 1.0 (the reference's default 1.4 diverges "
-                                  "on this cloud, CPU oracle and device alike), V(5,5)", 2, sides2, polys2,
-                             2 * a.vcycle_cycles, 5, oracle_cycles=0 if a.no_cpu else 3)
-            leg["setup_seconds"] = round(time.perf_counter() - t2, 1)
-            vcycles.insert(0, leg)
-            del mg2
-        except Exception as e:  # noqa: BLE001
-            vcycles.insert(0, {"workload": "BASELINE configs[1]", "error": str(e)})
+            multi["vcycle"] = distributed_vcycle_leg(a, rank, world, dist)
+        except Exception as e:  # noqa: BLE001 -- the sweep figures do not depend on this leg
+            multi["vcycle"] = {"error": str(e)}
 
     if rank == 0:
         if strong:
@@ -544,9 +625,14 @@ def main():
                 "launches": launches, "sweeps_in_launches": sweeps_timed,
                 "avg_launch_us": kern_ms * 1e3 / launches, "us_per_sweep": kern_ms * 1e3 / sweeps_timed,
                 "algorithmic_bytes_per_row": b_sor(stencil),
+                "frac_in_vcycle": achieved5 / HBM_PEAK_GBS, "achieved_in_vcycle": achieved5,
+                "in_vcycle": {"sweeps_per_launch": vc_sweeps, "launches": launches5,
+                              "avg_launch_us": kern_ms5 * 1e3 / max(launches5, 1), "us_per_sweep": kern_ms5 * 1e3 / vc_sweeps},
             },
         }
         out["spmv"] = spmv
+        if multi is not None:
+            out["multi_gpu"] = multi
         if vcycles:
             out["vcycle"] = vcycles
         if not dd and not a.no_fracstep and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:

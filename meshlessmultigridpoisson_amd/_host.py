@@ -554,7 +554,12 @@ class Multigrid:
             h = lib().mmgh_mg_extract_subdomain(self.h, int(nparts), int(rank))
         if not h:
             raise HostError(_err())
-        return Multigrid._from_handle(h, self.omega, self.iters)
+        sub = type(self)._from_handle(h, self.omega, self.iters)
+        sub.frac_step = bool(getattr(self, "frac_step", False))
+        for k in ("dt", "mu", "rho", "dim", "damping"):      # FracStepMultigrid: the flow parameters travel along
+            if hasattr(self, k):
+                setattr(sub, k, getattr(self, k))
+        return sub
 
     def gather_info(self):
         """(level, ranks, max_count, n_global, gid[ranks, max_count]) of a hierarchy with replicated coarse levels, or None."""

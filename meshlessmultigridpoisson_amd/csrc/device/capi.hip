@@ -341,6 +341,7 @@ struct mmg_hierarchy {
 };
 
 struct mmg_fracstep {
+    DevBuf<double> scal2;  // (sum, count) of fs_residual across the ranks
     mmg_level *p = nullptr;
     int n = 0, dim = 2;
     PlanGpu dx, dy, dz, lap;
@@ -736,8 +737,17 @@ int modify_coeff_neumann(mmg_level *lv, int coarse)
 // every interior row i -- s = b ./ diag on Neumann points, t = C s (gather plan), b -= t on interior points
 int push_inhomog(mmg_level *lv)
 {
-    if (lv->C.empty()) return MMG_OK;  // no coupling registered (implicitFlag_ false, grid.cpp:665)
+    if (lv->C.empty() && !(lv->distributed && lv->c_s.n > 0))
+        return MMG_OK;  // no coupling registered (implicitFlag_ false, grid.cpp:665)
+    if (lv->C.empty()) {  // a sub-domain without coupled rows still serves its neighbours' ghost refresh of s
+        HIPC(launch_div_masked(lv->c_s.p, lv->b.p, lv->c_diag.p, lv->flags8.p, lv->n, g_stream));
+        return exchange_vec(lv, lv->c_s.p);
+    }
     HIPC(launch_div_masked(lv->c_s.p, lv->b.p, lv->c_diag.p, lv->flags8.p, lv->n, g_stream));
+    // sub-domain level: s = b_j / a_jj is formed by the OWNER of a Neumann point; the interior rows of this rank also
+    // read s at ghost Neumann points (neumann_boundary_coeffs_ has those columns) -- one ghost refresh of s
+    if (lv->distributed)
+        if (int xrc = exchange_vec(lv, lv->c_s.p)) return xrc;
     TileArgs a{};
     a.p = lv->C.dev;
     a.n_list = lv->C.n_tiles;
@@ -2194,10 +2204,22 @@ int fs_apply(const PlanGpu &pl, const double *in, double *outv)
 }
 }  // namespace
 
+namespace {
+// Sub-domain grid (one rank of a decomposed FractionalStepGrid): the operators hold the rows of the OWNED points,
+// their columns reach into the ghost points -- the values there are refreshed from the owners before every operator
+// application, through the exchange lists of the pressure level (the vectors share its owned-then-ghost layout).
+int fs_refresh(mmg_fracstep *fs, double *vec)
+{
+    return fs->p->distributed ? exchange_vec(fs->p, vec) : MMG_OK;
+}
+}  // namespace
+
 int mmg_fracstep_calc_hat(mmg_fracstep *fs, double dt, double mu, double rho)
 {
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
+    if ((rc = fs_refresh(fs, fs->w[0].p)) || (rc = fs_refresh(fs, fs->w[1].p))) return rc;
+    if (fs->dim >= 3 && (rc = fs_refresh(fs, fs->w[4].p))) return rc;
     const double *u = fs->w[0].p, *v = fs->w[1].p;
     if (fs->dim >= 3) {  // third component: (u, v, w) . grad also carries w d/dz
         const int comp[3] = {0, 1, 4}, hat[3] = {2, 3, 5};
@@ -2227,6 +2249,8 @@ int mmg_fracstep_set_ppe_source(mmg_fracstep *fs, double dt, double rho)
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
     if ((rc = settle(fs->p))) return rc;
+    if ((rc = fs_refresh(fs, fs->w[2].p)) || (rc = fs_refresh(fs, fs->w[3].p))) return rc;   // u_hat, v_hat at the ghosts
+    if (fs->dim >= 3 && (rc = fs_refresh(fs, fs->w[5].p))) return rc;
     if ((rc = fs_apply(fs->dx, fs->w[2].p, fs->t1.p))) return rc;
     if ((rc = fs_apply(fs->dy, fs->w[3].p, fs->t2.p))) return rc;
     if (fs->dim >= 3) {
@@ -2247,6 +2271,7 @@ int mmg_fracstep_correct(mmg_fracstep *fs, double dt, double rho)
     if (!fs) return fail(MMG_ERR_INVALID, "null fracstep");
     int rc;
     if ((rc = settle(fs->p))) return rc;
+    if ((rc = fs_refresh(fs, fs->p->x.p))) return rc;   // the pressure at the ghosts
     if ((rc = fs_apply(fs->dx, fs->p->x.p, fs->t1.p))) return rc;
     HIPC(launch_fs_correct(fs->w[0].p, fs->w[2].p, fs->t1.p, dt / rho, fs->n, g_stream));
     if ((rc = fs_apply(fs->dy, fs->p->x.p, fs->t2.p))) return rc;
@@ -2325,12 +2350,26 @@ int mmg_fracstep_step(mmg_fracstep *fs, mmg_hierarchy *h, double dt, double mu, 
 int mmg_fracstep_residual(mmg_fracstep *fs, double *value)
 {
     if (!fs || !value) return fail(MMG_ERR_INVALID, "null argument");
-    HIPC(launch_abs_diff_sum(fs->w[0].p, fs->w[2].p, fs->n, fs->partial.p, g_stream));
-    HIPC(launch_sum_partials(fs->partial.p, abs_sum_blocks(fs->n), fs->scal.p, g_stream));
+    // sub-domain grid: the OWNED points of every rank, summed over the ranks, over the global point count
+    const int n_own = fs->p->distributed ? fs->p->n_owned : fs->n;
+    HIPC(launch_abs_diff_sum(fs->w[0].p, fs->w[2].p, n_own, fs->partial.p, g_stream));
+    HIPC(launch_sum_partials(fs->partial.p, abs_sum_blocks(n_own), fs->scal.p, g_stream));
+    double cnt = (double)n_own;
+    if (fs->p->distributed && g_rccl.comm && g_rccl.nranks > 1) {
+        if (fs->scal2.n == 0) HIPC(fs->scal2.alloc(2));
+        HIPC(hipMemcpyAsync(fs->scal2.p, fs->scal.p, sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        HIPC(hipMemcpyAsync(fs->scal2.p + 1, &cnt, sizeof(double), hipMemcpyHostToDevice, g_stream));
+        if (int rc = allreduce_sum(fs->scal2.p, 2)) return rc;
+        double hv[2] = {0, 0};
+        HIPC(hipMemcpyAsync(hv, fs->scal2.p, sizeof(hv), hipMemcpyDeviceToHost, g_stream));
+        HIPC(hipStreamSynchronize(g_stream));
+        *value = hv[0] / hv[1];
+        return MMG_OK;
+    }
     double h = 0;
     HIPC(hipMemcpyAsync(&h, fs->scal.p, sizeof(double), hipMemcpyDeviceToHost, g_stream));
     HIPC(hipStreamSynchronize(g_stream));
-    *value = h / fs->n;
+    *value = h / cnt;
     return MMG_OK;
 }
 

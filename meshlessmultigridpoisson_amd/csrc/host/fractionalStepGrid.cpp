@@ -60,6 +60,76 @@ FractionalStepGrid::~FractionalStepGrid()
     delete uvLaplaceMat_;
 }
 
+Grid *FractionalStepGrid::new_like(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source) const
+{
+    return new FractionalStepGrid(std::move(points), std::move(boundaries), properties, std::move(source));
+}
+
+void FractionalStepGrid::extra_ghost_columns(const vector<int> &part, int q, vector<int> &dst) const
+{
+    Grid::extra_ghost_columns(part, q, dst);
+    const int n = (int)points_.size();
+    for (const SparseRowMajor *m : {derivXMat_, derivYMat_, derivZMat_, uvLaplaceMat_}) {
+        if (!m) continue;
+        const int *rp = m->outerIndexPtr();
+        const int *col = m->innerIndexPtr();
+        for (int i = 0; i < n && i < m->rows(); ++i)
+            if (part[(size_t)i] == q)
+                for (int p = rp[i]; p < rp[i + 1]; ++p) dst.push_back(col[p]);
+    }
+}
+
+Grid *FractionalStepGrid::extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts)
+{
+    if (!derivXMat_ || !derivYMat_ || !uvLaplaceMat_ || (dim_ >= 3 && !derivZMat_))
+        throw std::runtime_error("FractionalStepGrid::extract_subdomain: build_deriv*/uv_laplace matrices first");
+    vector<int> extra;
+    if (extra_ghosts) extra = *extra_ghosts;
+    extra_ghost_columns(part, rank, extra);   // (again, in case the caller passed only the transfers' columns)
+    FractionalStepGrid *g = static_cast<FractionalStepGrid *>(Grid::extract_subdomain(part, rank, &extra));
+    const int n = (int)points_.size(), nl = (int)g->points_.size(), no = g->nOwned_;
+    vector<int> local((size_t)n, -1);
+    for (int k = 0; k < nl; ++k) local[(size_t)g->origIndex_[(size_t)k]] = k;
+    g->dt = dt;
+    g->ppe_conv_res = ppe_conv_res;
+    g->rho = rho;
+    g->mu = mu;
+    g->lambda = lambda;
+    g->flowType = flowType;
+    for (int k = no; k < nl; ++k) g->normalVecs_[(size_t)k] = normalVecs_[(size_t)g->origIndex_[(size_t)k]];
+    auto slice = [&](const SparseRowMajor *m) -> SparseRowMajor * {
+        if (!m) return nullptr;
+        const int *rp = m->outerIndexPtr();
+        const int *col = m->innerIndexPtr();
+        const double *val = m->valuePtr();
+        std::vector<int> outer((size_t)nl + 1, 0);
+        mmgh::RawVec<int> inner;
+        mmgh::RawVec<double> v;
+        for (int k = 0; k < no; ++k) {
+            const int i = g->origIndex_[(size_t)k];
+            for (int p = rp[i]; p < rp[i + 1]; ++p) {
+                if (local[(size_t)col[p]] < 0) throw std::runtime_error("FractionalStepGrid::extract_subdomain: an operator column is not a local point");
+                inner.push_back(local[(size_t)col[p]]);
+                v.push_back(val[p]);
+            }
+            outer[(size_t)k + 1] = (int)inner.size();
+        }
+        for (int k = no; k < nl; ++k) outer[(size_t)k + 1] = outer[(size_t)k];   // ghost points: no rows
+        SparseRowMajor *r = new SparseRowMajor(nl, nl, true);
+        r->adopt(std::move(outer), std::move(inner), std::move(v));
+        return r;
+    };
+    g->derivXMat_ = slice(derivXMat_);
+    g->derivYMat_ = slice(derivYMat_);
+    g->uvLaplaceMat_ = slice(uvLaplaceMat_);
+    g->derivZMat_ = slice(derivZMat_);
+    VectorXd *src[9] = {u, v, u_old, v_old, u_hat, v_hat, w, w_old, w_hat};
+    VectorXd *dst[9] = {g->u, g->v, g->u_old, g->v_old, g->u_hat, g->v_hat, g->w, g->w_old, g->w_hat};
+    for (int c = 0; c < 9; ++c)
+        for (int k = 0; k < nl; ++k) dst[c]->coeffRef(k) = src[c]->coeff(g->origIndex_[(size_t)k]);
+    return g;
+}
+
 namespace {
 // 3-D stand-in for the Kovasznay field (the reference has no 3-D flow): a smooth divergence-free velocity
 // (Taylor-Green shape) whose boundary values are non-trivial on every face of the unit cube

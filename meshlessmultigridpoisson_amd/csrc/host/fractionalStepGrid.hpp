@@ -45,6 +45,13 @@ public:
     // (a FractionalStepMultigrid whose finest grid is this one), device-resident (mmg_fracstep_step).
     // Returns fs_residual(); *cycles = V-cycles taken.
     double time_step(class Multigrid *mg, int max_cycles, int *cycles);
+    // Multi-GPU (BASELINE configs[4]): this rank's sub-domain as a FractionalStepGrid -- the rows of the owned points
+    // of D_x, D_y, (D_z,) and the velocity Laplacian with local columns (owned, then ghosts), the velocity state of
+    // the local points, the flow parameters.  The device refreshes the ghost values of u, v, w / the hats / the
+    // pressure from their owners in front of every operator (mmg_fracstep_*: "sub-domain grid").
+    Grid *extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr) override;
+    void extra_ghost_columns(const vector<int> &part, int q, vector<int> &dst) const override;
+    Grid *new_like(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source) const override;
 
 protected:
     SparseRowMajor *build_op(int which);

@@ -694,6 +694,23 @@ vector<int> Grid::partition_slabs(int nparts)
     return part;
 }
 
+Grid *Grid::new_like(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source) const
+{
+    return new Grid(std::move(points), std::move(boundaries), properties, std::move(source));
+}
+
+void Grid::extra_ghost_columns(const vector<int> &part, int q, vector<int> &dst) const
+{
+    if (!implicitFlag_ || !neumann_boundary_coeffs_ || neumann_boundary_coeffs_->nonZeros() == 0) return;
+    const int n = (int)points_.size();
+    if (neumann_boundary_coeffs_->rows() < n) return;
+    const int *rp = neumann_boundary_coeffs_->outerIndexPtr();
+    const int *col = neumann_boundary_coeffs_->innerIndexPtr();
+    for (int i = 0; i < n; ++i)
+        if (part[(size_t)i] == q)
+            for (int p = rp[i]; p < rp[i + 1]; ++p) dst.push_back(col[p]);
+}
+
 vector<std::pair<int, int>> Grid::ghost_list(const vector<int> &part, int rank, const vector<int> *extra_ghosts) const
 {
     const int n = (int)points_.size();
@@ -762,7 +779,7 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<in
             }
         bnds.push_back(nb);
     }
-    Grid *g = new Grid(pts, bnds, properties_, src);
+    Grid *g = new_like(pts, bnds, properties_, src);
     g->dim_ = dim_;
     g->implicitFlag_ = implicitFlag_;
     g->lanes_per_row_ = lanes_per_row_;
@@ -806,6 +823,30 @@ Grid *Grid::extract_subdomain(const vector<int> &part, int rank, const vector<in
     delete g->laplaceMat_;
     g->laplaceMat_ = new SparseRowMajor(a_loc, a_loc, true);
     g->laplaceMat_->adopt(std::move(outer), std::move(inner), std::move(v));
+    // push_inhomog_to_rhs (grid.cpp:664-685) on a sub-domain: the owned interior rows of neumann_boundary_coeffs_
+    // with local columns (Neumann points, owned or ghost) and the diagonal a_jj of every local point
+    for (int k = 0; k < nl; ++k) g->diags.coeffRef(k) = diags.coeff(g->origIndex_[(size_t)k]);
+    if (implicitFlag_ && neumann_boundary_coeffs_ && neumann_boundary_coeffs_->rows() >= n && neumann_boundary_coeffs_->nonZeros() > 0) {
+        const int *crp = neumann_boundary_coeffs_->outerIndexPtr();
+        const int *ccol = neumann_boundary_coeffs_->innerIndexPtr();
+        const double *cval = neumann_boundary_coeffs_->valuePtr();
+        std::vector<int> co((size_t)a_loc + 1, 0);
+        mmgh::RawVec<int> ci;
+        mmgh::RawVec<double> cv;
+        for (int k = 0; k < no; ++k) {
+            const int i = owned[(size_t)k];
+            for (int p = crp[i]; p < crp[i + 1]; ++p) {
+                if (local[(size_t)ccol[p]] < 0) throw std::runtime_error("extract_subdomain: a coupling column is not a local point");
+                ci.push_back(local[(size_t)ccol[p]]);
+                cv.push_back(cval[p]);
+            }
+            co[(size_t)k + 1] = (int)ci.size();
+        }
+        for (int k = no; k < a_loc; ++k) co[(size_t)k + 1] = co[(size_t)k];
+        delete g->neumann_boundary_coeffs_;
+        g->neumann_boundary_coeffs_ = new SparseRowMajor(a_loc, a_loc, true);
+        g->neumann_boundary_coeffs_->adopt(std::move(co), std::move(ci), std::move(cv));
+    }
     // tiles: the owned part of every global tile, in order
     if (!tile_ptr_.empty()) {
         g->tile_ptr_.push_back(0);

@@ -84,6 +84,8 @@ public:
 
     Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source);
     virtual ~Grid();
+    // the object extract_subdomain fills for a sub-domain: a Grid here, a FractionalStepGrid in the derived class
+    virtual Grid *new_like(vector<Point> points, vector<Boundary> boundaries, GridProperties properties, VectorXd source) const;
     Grid(const Grid &) = delete;
     Grid &operator=(const Grid &) = delete;
 
@@ -125,7 +127,11 @@ public:
     // lists, RHS and tile boundaries restricted accordingly.  `extra_ghosts` (global indices)
     // are kept as ghosts even if no owned row references them (transfer operators need them).
     // Neumann grids keep a replicated multiplier unknown (all-reduced on the device).
-    Grid *extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr);
+    virtual Grid *extract_subdomain(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr);
+    // Columns (global point ids) that the rows owned by rank q read through operators OTHER than laplaceMat_ and the
+    // transfers: neumann_boundary_coeffs_ here (push_inhomog_to_rhs); FractionalStepGrid adds D_x, D_y, (D_z,) and the
+    // velocity Laplacian.  Multigrid::extract_subdomain adds them to every rank's ghost list.
+    virtual void extra_ghost_columns(const vector<int> &part, int q, vector<int> &dst) const;
     // The ghost list extract_subdomain(part, rank, extra_ghosts) would produce -- (owner, global index),
     // sorted -- without building the sub-domain: lets every rank work out what its neighbours need from it.
     vector<std::pair<int, int>> ghost_list(const vector<int> &part, int rank, const vector<int> *extra_ghosts = nullptr) const;

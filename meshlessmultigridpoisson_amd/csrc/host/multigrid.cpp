@@ -218,6 +218,8 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
         // (R into a replicated level reads the all-gathered residual, not ghosts)
         for (size_t l = std::max<size_t>(1, l_agg + 1); l < nl; ++l) need(restrictionMatrices_[l], part[l - 1], q, ex[l]);  // R_l : level l -> l-1
         for (size_t l = 0; l + 1 < nl; ++l) need(prolongMatrices_[l], part[l + 1], q, ex[l]);  // P_l : level l -> l+1
+        // operators of the level itself besides laplaceMat_ (Neumann coupling; D_x, D_y, D_z, velocity Laplacian)
+        for (size_t l = l_agg; l < nl; ++l) grids_[l].second->extra_ghost_columns(part[l], q, ex[l]);
         return ex;
     };
     vector<vector<int>> extra = extras_of(rank);

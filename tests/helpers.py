@@ -115,7 +115,7 @@ def oracle_of_fracstep(g):
     return oc.FracStep(g.sizes()["n"], g.op(0), g.op(1), g.op(2), nx, ny, bpts)
 
 
-def oracle_fracstep_time_step(om, ofs, g_arrays, dt, mu, rho, tol, max_cycles):
+def oracle_fracstep_time_step(om, ofs, g_arrays, dt, mu, rho, tol, max_cycles, vcycle=None):
     """One time step of run_fracstep_param (FractionalStepSim.cpp:131-147) with oracle objects: om the oracle
     Multigrid (frac_step), ofs the oracle FracStep(3) of its finest grid, g_arrays = dict(bpts, bvals (list of per-
     component boundary value arrays), coupling=((rp, col, val), diag), bcflags).  Returns (fs_residual, cycles)."""
@@ -130,7 +130,7 @@ def oracle_fracstep_time_step(om, ofs, g_arrays, dt, mu, rho, tol, max_cycles):
     oc.push_inhomog(n, g_arrays["coupling"][0], g_arrays["coupling"][1], g_arrays["bcflags"], fine.b)
     cycles = 0
     while om.residual() >= tol and cycles < max_cycles:
-        om.vcycle()
+        (vcycle or om.vcycle)()          # vcycle: e.g. the multi-GPU relaxation schedule, om.vcycle_hybrid(parts, n)
         fine.bound_eval_neumann()
         cycles += 1
     ofs.correct(fine.x[:n], dt, rho)

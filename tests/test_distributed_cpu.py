@@ -234,6 +234,7 @@ class _Rank:
     """One rank's view of a decomposed hierarchy, arithmetic by the plan interpreter."""
 
     def __init__(self, host, sub, rank, hints=False):
+        self.rank = rank
         self.nl = sub.nlevels
         self.lv, self.maps, self.la, self.R, self.P = [], [], [], [None] * self.nl, [None] * self.nl
         for l in range(self.nl):
@@ -261,7 +262,38 @@ class _Rank:
                                if la["btype"][b] == 2] + [np.zeros(0, dtype=np.int32)]).astype(np.int64)
 
 
+_COMM = None   # None: all ranks live in this process (lists of _Rank); else torch.distributed (one _Rank per process)
+
+
+def _allsum(values):
+    """ncclAllReduce(sum) of one scalar per rank."""
+    s = float(sum(values))
+    if _COMM is None:
+        return s
+    import torch
+    t = torch.tensor([s], dtype=torch.float64)
+    _COMM.all_reduce(t)
+    return float(t.item())
+
+
 def _exchange(ranks, l, get, put):
+    if _COMM is not None:          # grouped ncclSend / ncclRecv as gloo isend / irecv
+        import torch
+        (rk,) = ranks
+        nbr, sp, si, rp = rk.lists[l]
+        no = rk.maps[l][0]
+        reqs, recv = [], []
+        for k, q in enumerate(nbr):
+            sb = torch.from_numpy(np.ascontiguousarray(get(rk)[si[sp[k]:sp[k + 1]]], dtype=np.float64).copy())
+            rb = torch.empty(int(rp[k + 1] - rp[k]), dtype=torch.float64)
+            reqs.append(_COMM.isend(sb, int(q)))
+            reqs.append(_COMM.irecv(rb, int(q)))
+            recv.append((k, rb))
+        for rq in reqs:
+            rq.wait()
+        for k, rb in recv:
+            put(rk)[no + rp[k]: no + rp[k + 1]] = rb.numpy()
+        return
     out = {}
     for r, rk in enumerate(ranks):
         nbr, sp, si, rp = rk.lists[l]
@@ -293,7 +325,7 @@ def _dist_sweeps(ranks, l, k, exact=False):
             for rk in ranks:
                 rk.lv[l].sor_phases()
         if neumann:
-            S = sum(rk.lv[l].owned_sum() for rk in ranks)          # ncclAllReduce
+            S = _allsum(rk.lv[l].owned_sum() for rk in ranks)      # ncclAllReduce
             for rk, nn in zip(ranks, n):
                 e = rk.lv[l]
                 xi = (e.b[nn] - S) * (e.omega / 1.0) + (1.0 - e.omega) * e.x[nn]
@@ -312,15 +344,16 @@ def _dist_residual(ranks, l):
     neumann = ranks[0].la[l]["neumann"]
     _exchange(ranks, l, lambda rk: rk.lv[l].x, lambda rk: rk.lv[l].x)
     rs, nr, nb = [], 0.0, 0.0
-    S = sum(rk.lv[l].owned_sum() for rk in ranks) if neumann else 0.0
-    for r, rk in enumerate(ranks):
+    S = _allsum(rk.lv[l].owned_sum() for rk in ranks) if neumann else 0.0
+    for rk in ranks:
         e, nn, no = rk.lv[l], rk.la[l]["n"], rk.maps[l][0]
         rv, _ = e.residual()
         if neumann:
             rv[nn] = e.b[nn] - (S + e.x[nn])
         rs.append(rv)
-        nr += np.abs(rv[:no]).sum() + (abs(rv[nn]) if neumann and r == 0 else 0.0)
-        nb += np.abs(e.b[:no]).sum() + (abs(e.b[nn]) if neumann and r == 0 else 0.0)
+        nr += np.abs(rv[:no]).sum() + (abs(rv[nn]) if neumann and rk.rank == 0 else 0.0)
+        nb += np.abs(e.b[:no]).sum() + (abs(e.b[nn]) if neumann and rk.rank == 0 else 0.0)
+    nr, nb = _allsum([nr]), _allsum([nb])
     for rk, rv in zip(ranks, rs):
         rk._r = rv
     _exchange(ranks, l, lambda rk: rk._r, lambda rk: rk._r)
@@ -664,3 +697,177 @@ def test_per_phase_exchange_is_sequential_gauss_seidel(nr):
     for r, e in enumerate(emus):
         xh[loc2new[r][:maps[r][0]]] = e.x[:maps[r][0]]
     assert H.rel_err(xh, o.x) > 1e-6
+
+
+# ---- distributed fractional step (BASELINE configs[4]): the time loop of FractionalStepSim.cpp:130-156 over ranks ----
+class _FsRank:
+    """One rank's FractionalStepGrid sub-domain as arrays: the owned rows of D_x, D_y, the velocity Laplacian and of
+    neumann_boundary_coeffs_ (local columns: owned, then ghosts), velocity state of the local points."""
+
+    def __init__(self, sg):
+        import scipy.sparse as sp
+        self.n = sg.sizes()["n"]
+        self.no = sg.local_map()[0]
+        self.ops = [sp.csr_matrix((v, c, rp), shape=(self.n, self.n)) for (rp, c, v) in (sg.op(0), sg.op(1), sg.op(2))]
+        self.nx, self.ny = sg.normals()
+        _bt, _bp, self.bpts, _bv = sg.boundaries()
+        (rp, c, v), self.diag = sg.coupling()
+        self.C = sp.csr_matrix((v, c, rp[: self.n + 1]), shape=(self.n, self.n))
+        _xyz, self.flags = sg.points()
+        self.u, self.v, self.uh, self.vh = sg.vec(0), sg.vec(1), sg.vec(2), sg.vec(3)
+        self.bu, self.bv = self.u[self.bpts].copy(), self.v[self.bpts].copy()    # set_uv_bound's values
+        self.s = np.zeros(self.n)
+
+
+def _dist_fracstep_time_step(ranks, fs, dt, mu, rho, tol, max_cycles):
+    """mmg_fracstep_step (capi.hip) on sub-domain grids, step by step, ghost refreshes where the device does them."""
+    fl = len(ranks[0].lv) - 1
+
+    def refresh(name):
+        _exchange(ranks, fl, lambda rk: getattr(fs[ranks.index(rk)], name), lambda rk: getattr(fs[ranks.index(rk)], name))
+    for f in fs:                                   # set_uv_bound
+        f.u[f.bpts], f.v[f.bpts] = f.bu, f.bv
+    refresh("u")
+    refresh("v")
+    for f in fs:                                   # predictor (fractionalStepGrid.cpp:101-124), owned rows
+        for w, out in ((f.u, "uh"), (f.v, "vh")):
+            fx, fy, l2 = f.ops[0] @ w, f.ops[1] @ w, f.ops[2] @ w
+            setattr(f, out, w + dt * (-(f.u * fx + f.v * fy) + mu / rho * l2))
+    refresh("uh")
+    refresh("vh")
+    for rk, f in zip(ranks, fs):                   # PPE source (:125-145)
+        b = rk.lv[fl].b
+        b[: f.n] = rho / dt * (f.ops[0] @ f.uh + f.ops[1] @ f.vh)
+        p = f.bpts
+        b[p] = f.nx[p] * (-rho / dt * (f.u[p] - f.uh[p])) + f.ny[p] * (-rho / dt * (f.v[p] - f.vh[p]))
+        f.s[:] = 0.0                               # push_inhomog_to_rhs (grid.cpp:664-685): s = b_j / a_jj at the owner
+        own_neu = np.flatnonzero(f.flags[: f.no] == 2)
+        f.s[own_neu] = b[own_neu] / f.diag[own_neu]
+    refresh("s")
+    for rk, f in zip(ranks, fs):
+        t = f.C @ f.s
+        interior = np.flatnonzero(f.flags[: f.no] == 0)
+        rk.lv[fl].b[interior] -= t[interior]
+    cycles = 0
+    while True:                                    # while (mg.residual() >= tol) { vCycle(); bound_eval_neumann(); }
+        ratio = _dist_residual(ranks, fl)
+        if not (ratio >= tol) or cycles >= max_cycles:
+            break
+        _dist_vcycle(ranks)
+        _exchange(ranks, fl, lambda rk: rk.lv[fl].x, lambda rk: rk.lv[fl].x)
+        for rk in ranks:
+            rk.lv[fl].bound_eval()
+        cycles += 1
+    _exchange(ranks, fl, lambda rk: rk.lv[fl].x, lambda rk: rk.lv[fl].x)
+    for rk, f in zip(ranks, fs):                   # corrector (:146-151)
+        p = rk.lv[fl].x[: f.n]
+        f.u = f.uh - dt / rho * (f.ops[0] @ p)
+        f.v = f.vh - dt / rho * (f.ops[1] @ p)
+        f.u[f.bpts], f.v[f.bpts] = f.bu, f.bv
+    num = _allsum(np.abs(f.u[: f.no] - f.uh[: f.no]).sum() for f in fs)      # fs_residual: owned points, all-reduced
+    return num / _allsum(f.no for f in fs), cycles
+
+
+@pytest.mark.parametrize("nparts", [2, 3])
+def test_distributed_fractional_step_matches_hybrid_oracle(nparts):
+    """BASELINE configs[4] in form: FractionalStepMultigrid::extract_subdomain gives every rank a FractionalStepGrid
+    sub-domain (owned rows of D_x, D_y, lap, of the Neumann coupling; ghost columns); the emulated distributed time
+    step -- ghost refresh of u, v before the predictor, of the hats before the PPE source, of s = b_j / a_jj inside
+    push_inhomog_to_rhs, the distributed pressure loop, ghost refresh of p before the corrector, all-reduced
+    fs_residual -- must follow the time loop of FractionalStepSim.cpp:131-147 over oracle objects on the GLOBAL grid
+    whose V-cycle relaxes in the multi-GPU schedule (orc_vcycle_hybrid).  Per-rank level arithmetic by the plan
+    interpreter; two time steps, six V-cycles each."""
+    from meshlessmultigridpoisson_amd import _host as host
+    clouds = [host.quasi_uniform_square_cloud(n) for n in (13, 25)]
+    mg = host.FracStepMultigrid(clouds, [3, 3], dim=2, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=96)
+    g = mg.fs_grid()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    g.set_uv_bound()
+    om = H.oracle_of_multigrid(mg)
+    ofs = H.oracle_of_fracstep(g)
+    ofs.u[:], ofs.v[:] = g.vec(0), g.vec(1)
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[ofs.u[bpts].copy(), ofs.v[bpts].copy()], coupling=g.coupling(), bcflags=flags)
+    parts = [mg.level_part(l, nparts) for l in range(mg.nlevels)]
+    subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
+    ranks = [_Rank(host, s, r) for r, s in enumerate(subs)]
+    for rk, sub in zip(ranks, subs):
+        rk.lists = [sub.grid(l).exchange_lists() for l in range(sub.nlevels)]
+        assert all(x is not None for x in rk.lists)
+    fs = [_FsRank(sub.fs_grid()) for sub in subs]
+    for r, f in enumerate(fs):                      # sub-domain state = the global state at the local points
+        gid = ranks[r].maps[-1][1]
+        assert np.array_equal(f.u, ofs.u[gid]) and np.array_equal(f.v, ofs.v[gid])
+    for step in range(2):
+        r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6,
+                                                    vcycle=lambda: om.vcycle_hybrid(parts, nparts))
+        r_dist, nc_dist = _dist_fracstep_time_step(ranks, fs, g.dt, g.mu, g.rho, 1e-10, 6)
+        assert nc_dist == nc_orc == 6
+        assert abs(r_dist - r_orc) <= 1e-9 * abs(r_orc), (step, r_dist, r_orc)
+        for r, (rk, f) in enumerate(zip(ranks, fs)):
+            no, gid, _ = rk.maps[-1]
+            assert np.abs(f.u[:no] - ofs.u[gid[:no]]).max() <= 1e-9 * np.abs(ofs.u).max(), (step, r)
+            assert np.abs(f.v[:no] - ofs.v[gid[:no]]).max() <= 1e-9 * np.abs(ofs.v).max(), (step, r)
+            assert np.abs(rk.lv[-1].x[:no] - om.levels[-1].x[gid[:no]]).max() <= 1e-9 * np.abs(om.levels[-1].x).max()
+
+
+def _fs_problem(host):
+    clouds = [host.quasi_uniform_square_cloud(n) for n in (13, 25)]
+    mg = host.FracStepMultigrid(clouds, [3, 3], dim=2, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=96)
+    g = mg.fs_grid()
+    g.prescribe_soln()
+    g.set_uv_bound()
+    return mg, g
+
+
+def _gloo_fracstep_worker(rank, world, port, out_dir):
+    """One process per rank, torch.distributed / gloo instead of RCCL: the rank sees only its own sub-domain objects;
+    ghost refreshes are isend / irecv pairs, scalars all_reduce -- the communication pattern of mmg_fracstep_step."""
+    global _COMM
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, H.ROOT)
+    from meshlessmultigridpoisson_amd import _host as host
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _COMM = dist
+    mg, g = _fs_problem(host)
+    sub = mg.extract_subdomain(world, rank)
+    rk = _Rank(host, sub, rank)
+    rk.lists = [sub.grid(l).exchange_lists() for l in range(sub.nlevels)]
+    f = _FsRank(sub.fs_grid())
+    out = []
+    for _step in range(2):
+        out.append(_dist_fracstep_time_step([rk], [f], g.dt, g.mu, g.rho, 1e-10, 6))
+    no, gid, _ = rk.maps[-1]
+    np.savez(os.path.join(out_dir, f"fs_rank{rank}.npz"), u=f.u[:no], v=f.v[:no], p=rk.lv[-1].x[:no], gid=gid[:no],
+             res=np.array([o[0] for o in out]), cycles=np.array([o[1] for o in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world_size_2_fractional_step(tmp_path):
+    """The distributed fractional step as two real processes over torch.distributed (gloo): every rank builds its
+    sub-domain with FractionalStepMultigrid::extract_subdomain, runs two time steps exchanging only through
+    send / recv / all_reduce, and the glued result equals the oracle loop on the global grid (hybrid schedule)."""
+    import torch.multiprocessing as mp
+    from meshlessmultigridpoisson_amd import _host as host
+    port = _free_port()
+    mp.spawn(_gloo_fracstep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mg, g = _fs_problem(host)
+    om, ofs = H.oracle_of_multigrid(mg), H.oracle_of_fracstep(g)
+    ofs.u[:], ofs.v[:] = g.vec(0), g.vec(1)
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[ofs.u[bpts].copy(), ofs.v[bpts].copy()], coupling=g.coupling(), bcflags=flags)
+    parts = [mg.level_part(l, 2) for l in range(mg.nlevels)]
+    want = [H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6, vcycle=lambda: om.vcycle_hybrid(parts, 2))
+            for _ in range(2)]
+    for r in range(2):
+        z = np.load(tmp_path / f"fs_rank{r}.npz")
+        assert list(z["cycles"]) == [w[1] for w in want]
+        assert np.allclose(z["res"], [w[0] for w in want], rtol=1e-9, atol=0)
+        assert np.abs(z["u"] - ofs.u[z["gid"]]).max() <= 1e-9 * np.abs(ofs.u).max()
+        assert np.abs(z["v"] - ofs.v[z["gid"]]).max() <= 1e-9 * np.abs(ofs.v).max()
+        assert np.abs(z["p"] - om.levels[-1].x[z["gid"]]).max() <= 1e-9 * np.abs(om.levels[-1].x).max()

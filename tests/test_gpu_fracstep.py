@@ -143,3 +143,49 @@ def test_3d_time_step_converges_to_the_ppe_tolerance(host):
         assert np.isfinite(r_dev) and abs(r_dev - r_orc) <= 1e-6 * abs(r_orc), (step, r_dev, r_orc)
         for got, want in zip(_vecs(g), comps):
             assert H.rel_err(got, want) < 1e-6, step
+
+
+@pytest.mark.parametrize("dim,sides,deg", [(2, [15, 29], 3), (3, [7, 13], 2)])
+def test_distributed_time_step_single_rank_loopback(host, dim, sides, deg):
+    """BASELINE configs[4]'s code path on one GPU: FractionalStepMultigrid::extract_subdomain(1, 0) gives a
+    sub-domain hierarchy whose finest grid is a FractionalStepGrid sub-domain; with a communicator of one rank and the
+    exchange lists registered (Multigrid::setup_exchange) mmg_fracstep_step takes its DISTRIBUTED branches -- ghost
+    refresh of u, v, w / the hats / s / p in front of the operators, distributed V-cycle, fs_residual over the owned
+    points -- and must reproduce the oracle loop on the undecomposed grid (one rank: hybrid schedule = sequential).
+    2 and 3 ranks: CPU emulation and gloo world_size 2, tests/test_distributed_cpu.py."""
+    from meshlessmultigridpoisson_amd import _capi
+    cloud = (lambda n, s: host.square_cloud(n, seed=s)) if dim == 2 else (lambda n, s: host.box_cloud(n, 3, seed=s, edges=False))
+    clouds = [cloud(n, 4321 + i) for i, n in enumerate(sides)]
+    mg = host.FracStepMultigrid(clouds, [deg] * len(sides), dim=dim, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC,
+                                tile_points=128)
+    g = mg.fs_grid()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    g.set_uv_bound()
+    om = H.oracle_of_multigrid(mg)
+    ofs = H.oracle_of_fracstep(g)
+    comps = [ofs.u, ofs.v] + ([ofs.w] if dim == 3 else [])
+    for c, vals in zip(comps, _vecs(g)):
+        c[:] = vals
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[c[bpts].copy() for c in comps], coupling=g.coupling(), bcflags=flags)
+    sub = mg.extract_subdomain(1, 0)
+    sg = sub.fs_grid()
+    assert sg.sizes()["n"] == n and sg.local_map()[0] == n
+    for got, want in zip(_vecs(sg), comps):          # the velocity state travelled with the sub-domain
+        assert np.array_equal(got, want)
+    _capi.comm_init(0, 1, _capi.comm_unique_id())
+    try:
+        assert _capi.comm_info() == (1, 0)           # read back from RCCL
+        sub.setup_exchange_native(exact=False)
+        for step in range(2):
+            r_dev, nc_dev = sub.step(max_cycles=6)
+            r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6)
+            assert nc_dev == nc_orc == 6, (step, nc_dev, nc_orc)
+            for got, want in zip(_vecs(sg), comps):
+                assert H.rel_err(got, want) < 1e-9, step
+            assert H.rel_err(sg.values()[:n], om.levels[-1].x[:n]) < 1e-9, step
+            assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)
+    finally:
+        _capi.comm_finalize()
