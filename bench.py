@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-vcycle", action="store_true", help="skip the whole-V-cycle legs")
     ap.add_argument("--dd-vcycle-nside", type=int, default=128,
                     help="N>1: points per axis of the ONE cloud of the distributed V-cycle leg (every rank builds the global hierarchy)")
+    ap.add_argument("--fracstep-nside", type=int, default=72,
+                    help="N>1: points per axis of the ONE cloud of the distributed fractional-step leg (configs[4] itself: 216)")
     ap.add_argument("--replicate-below", type=int, default=70000,
                     help="N>1 V-cycle leg: levels with fewer points are kept complete on every rank")
     ap.add_argument("--no-fracstep", action="store_true", help="skip the 3-D fractional-step leg (N=1)")
@@ -287,6 +289,48 @@ def distributed_vcycle_leg(a, rank, world, dist):
             "setup_seconds_max_over_ranks": round(t_setup, 1),
             "residual_history": [float(r) for r in res[:4]],
             "contraction_per_cycle": float((res[-1] / res[0]) ** (1.0 / max(1, len(res) - 1))) if res[0] > 0 else None}
+
+
+def distributed_fracstep_leg(a, rank, world, dist, steps=2, coarse_iters=60):
+    """BASELINE configs[4] in form: the fractional-step time loop (FractionalStepSim.cpp:130-156) over `world` GPUs.
+    Every rank builds the same global two-level FractionalStepMultigrid (--fracstep-nside^3 points), keeps its x-slab
+    as FractionalStepGrid sub-domains (FractionalStepMultigrid::extract_subdomain) and runs mmg_fracstep_step: ghost
+    refresh of u, v, w / the hats / the pressure in front of every operator, the distributed pressure loop to 1e-10,
+    all-reduced fs_residual.  Time = max over ranks of the wall time per time step."""
+    from meshlessmultigridpoisson_amd import _host
+    t0 = time.perf_counter()
+    ns = a.fracstep_nside
+    sides = [ns // 2, ns]
+    clouds = [_host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate(sides)]
+    mg = _host.FracStepMultigrid(clouds, [3, 3], dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=_host.ORDER_MC, tile_points=0)
+    mg.grid(0).set_relaxation(1.4, coarse_iters)
+    g = mg.fs_grid()
+    g.prescribe_soln()
+    g.set_uv_bound()
+    n_glob = g.sizes()["n"]
+    sub = mg.extract_subdomain(world, rank)
+    del mg
+    sub.setup_exchange_native(exact=False)
+    t_setup = time.perf_counter() - t0
+    sub.step(max_cycles=3)
+    recs = []
+    for _ in range(steps):
+        t = time.perf_counter()
+        r, nc = sub.step(max_cycles=600)
+        recs.append((time.perf_counter() - t, nc, r))
+    sec = float(np.median([x[0] for x in recs]))
+    if dist is not None:
+        import torch
+        t = torch.tensor([sec, t_setup], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec, t_setup = float(t[0].item()), float(t[1].item())
+    cyc = int(np.median([x[1] for x in recs]))
+    return {"workload": f"3-D fractional step (FractionalStepSim.cpp:130-156) on ONE {ns}^3 cloud ({n_glob} points) over {world} GPUs "
+                        f"(x-slabs), levels {sides}, RBF-FD degree 3 (K=50), dt 1e-3, pressure loop to 1e-10, {coarse_iters} sweeps on "
+                        f"the coarse grid; BASELINE configs[4] names 1e7 points (--fracstep-nside 216)",
+            "points": n_glob, "seconds_per_time_step_max_over_ranks": sec, "vcycles_per_time_step": cyc,
+            "pressure_loop_converged": bool(cyc < 600), "fs_residual": float(recs[-1][2]),
+            "setup_seconds_max_over_ranks": round(t_setup, 1)}
 
 
 def spawn_ranks(a):
@@ -578,6 +622,11 @@ def main():
             multi["vcycle"] = distributed_vcycle_leg(a, rank, world, dist)
         except Exception as e:  # noqa: BLE001 -- the sweep figures do not depend on this leg
             multi["vcycle"] = {"error": str(e)}
+    if dd and not a.no_fracstep and a.operator == "rbf" and a.dim == 3:
+        try:
+            multi["fracstep"] = distributed_fracstep_leg(a, rank, world, dist)
+        except Exception as e:  # noqa: BLE001
+            multi["fracstep"] = {"error": str(e)}
 
     if rank == 0:
         if strong:

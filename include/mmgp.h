@@ -93,7 +93,7 @@ typedef struct {
     long long stream_bytes;  /* packed bytes read per sweep (matrix stream)     */
     long long halo_entries;  /* ghost-of-tile values staged per sweep           */
     long long neumann_rows;
-    int waves_per_tile;      /* 1: packed stream, one wavefront per tile; > 1: dense layout */
+    int waves_per_tile;      /* 1: packed stream, one wavefront per tile; > 1: dense layout; -1: dense layout, one wavefront per tile */
     int max_tile_levels;     /* longest dependency chain (levels of coupled rows) inside one tile */
 } mmg_level_info;
 
@@ -124,6 +124,9 @@ int mmg_get_counter(const char *name, long long *value);
  * iterates and residual histories are then bitwise those of the sequential CPU loops
  * (grid.cpp:104-151, multigrid.cpp:62-115).  Slow; proves the schedule is the
  * reference's Gauss-Seidel order.
+ * "dense_single" (1/0): automatic layout only -- a dense level whose rounds are under 40 % full (levels relaxed in a sweep
+ * order: ~4 uncoupled rows per dependency level) is rebuilt with ONE wavefront per tile (waves_per_tile = -1); 0 keeps
+ * the multi-wavefront rounds (A/B).
  * "debug_fail_graph" (0/1): test hook -- the next instantiation of a captured V-cycle body "fails", the body is
  * issued with plain launches from then on (continuing from the flag epochs in front of the failed capture).
  * "waves_per_tile": layout of levels created afterwards whose descriptor leaves it 0 -- 0 automatic (by

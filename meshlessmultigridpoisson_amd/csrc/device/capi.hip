@@ -50,6 +50,7 @@ int g_graph = 0;
 thread_local bool g_capturing = false;  // inside hipStreamBeginCapture ... EndCapture of a cycle body
 unsigned long long g_state_gen = 1;     // bumped by everything a captured cycle body depends on besides its data
 int g_spin_bound = 1 << 22;        // mmg_set_option("debug_spin_bound", n): test hook, 0 makes every wait fail
+int g_dense_single = 1;            // mmg_set_option("dense_single", 0): never rebuild a sparse dense level with one wavefront per tile (A/B)
 int g_debug_fail_graph = 0;        // mmg_set_option("debug_fail_graph", 1): test hook, the next graph instantiation "fails"
 long long g_sweep_fallbacks = 0;   // mmg_get_counter("sweep_fallbacks")
 
@@ -1031,6 +1032,7 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "waves_per_tile") == 0) { g_waves = value; return MMG_OK; }
     if (std::strcmp(name, "debug_spin_bound") == 0) { g_spin_bound = value < 0 ? (1 << 22) : value; return MMG_OK; }
     if (std::strcmp(name, "debug_fail_graph") == 0) { g_debug_fail_graph = value; return MMG_OK; }
+    if (std::strcmp(name, "dense_single") == 0) { g_dense_single = value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 
@@ -1227,18 +1229,33 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
     {
         Plan P;
         const double avg_row = (double)d->rowptr[d->n] / std::max(1, d->n);
-        int waves = d->waves_per_tile > 0 ? d->waves_per_tile : g_waves;
+        int waves = d->waves_per_tile != 0 ? d->waves_per_tile : g_waves;
+        const bool automatic = waves == 0;
         mmg_level_desc dd = *d;  // the automatic layout also picks the lanes per row of its dense shape
-        if (waves <= 0) {
+        if (waves == 0) {
             const LevelLayout ll = level_layout(d->n, avg_row);
             waves = ll.dense ? ll.waves : 1;
             if (ll.dense && d->lanes_per_row <= 0) dd.lanes_per_row = ll.lanes;
         }
-        if (!(waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8 || waves == 12))
-            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be 0, 1, 2, 3, 4, 6, 8 or 12");
+        if (!(waves == -1 || waves == 1 || waves == 2 || waves == 3 || waves == 4 || waves == 6 || waves == 8 || waves == 12))
+            return fail(MMG_ERR_INVALID, "level_create: waves_per_tile must be -1, 0, 1, 2, 3, 4, 6, 8 or 12");
         std::unique_ptr<StageTimer> st(new StageTimer("level_create: build_level_plan"));
-        const std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
+        std::string err = build_level_plan(dd, L, &P, g_exact, g_slot_bits, waves);
         if (!err.empty()) return fail(MMG_ERR_UNSUPPORTED, "level plan: " + err);
+        // Levels relaxed in a SWEEP order (Grid::mc_order_points point order 2, the reference's RCM order) have only a
+        // handful of mutually uncoupled rows per dependency level: rounds of several dense groups are then mostly
+        // empty row slots (1500 instead of 370 B per row at K = 37) and the level is bound by the padding it streams.
+        // With under 40 % of the row slots filled the dense layout is rebuilt with ONE wavefront per tile (rounds of a
+        // single group, 8 lanes per row; kernels: 2-D shapes only).
+        if (automatic && g_dense_single && !g_exact && P.dense && !P.dense_long && P.waves > 1 && avg_row < 44.0 && P.dense_plen <= 5 && P.n_groups > 0 &&
+            (double)P.n_rows < 0.4 * (double)P.n_groups * (64 / P.L)) {
+            Plan P1;
+            mmg_level_desc d1 = dd;
+            d1.lanes_per_row = 8;
+            if (build_level_plan(d1, L, &P1, false, g_slot_bits, -1).empty() && P1.dense && P1.waves == 1 && P1.L == 8 &&
+                P1.dense_plen <= 5)
+                P = std::move(P1);
+        }
         lv->A.exact = g_exact;
         st.reset(new StageTimer("level_create: upload"));
         if ((rc = lv->A.upload(P))) return rc;
@@ -1308,7 +1325,7 @@ int mmg_level_info_get(const mmg_level *lv, mmg_level_info *info)
     info->stream_bytes = lv->A.stream_bytes;
     info->halo_entries = lv->A.halo_entries;
     info->neumann_rows = lv->B.n_rows;
-    info->waves_per_tile = lv->A.dev.dense ? lv->A.dev.waves : 1;
+    info->waves_per_tile = lv->A.dev.dense ? (lv->A.dev.waves == 1 ? -1 : lv->A.dev.waves) : 1;
     info->max_tile_levels = lv->A.max_levels;
     return MMG_OK;
 }

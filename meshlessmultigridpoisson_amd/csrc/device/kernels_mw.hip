@@ -429,6 +429,9 @@ template <int L, int P>
 hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t s, int *occ)
 {
     switch (a.p.waves) {
+    case 1:   // one wavefront per tile: the sweep-ordered 2-D levels (rounds of ~4 rows)
+        if constexpr (L == 8 && P <= 5) return launch_mw_LPN<L, P, 1>(k, a, workers, s, occ);
+        break;
     case 2: return launch_mw_LPN<L, P, 2>(k, a, workers, s, occ);
     case 3: return launch_mw_LPN<L, P, 3>(k, a, workers, s, occ);
     case 4: return launch_mw_LPN<L, P, 4>(k, a, workers, s, occ);

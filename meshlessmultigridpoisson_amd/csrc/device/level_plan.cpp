@@ -55,18 +55,22 @@ int dense_lanes(int lanes_per_row, double avg_row_len)
 
 std::string build_level_plan(const mmg_level_desc &d, int L, Plan *out, bool exact, int slot_bits, int waves, bool dense_long)
 {
-    if (waves > 1 && !exact) {  // dense layout first; rows too long for it -> rows over several row slots -> packed layout
+    // waves: 1 packed stream; k > 1 dense layout with k wavefronts per tile; -1 dense layout with ONE wavefront per tile
+    // (levels relaxed in sweep order: ~4 mutually uncoupled rows per dependency level, a round of several groups would
+    // be mostly padding).  Internally -(1000 + k) asks for the dense layout with k wavefronts.
+    if ((waves > 1 || waves == -1) && !exact) {  // dense layout first; rows too long for it -> rows over several row slots -> packed layout
+        const int wd = waves == -1 ? 1 : waves;
         const int Ld = dense_lanes(d.lanes_per_row, (double)d.rowptr[d.n] / std::max(1, d.n));
-        std::string derr = build_level_plan(d, Ld, out, false, 16, -waves);
+        std::string derr = build_level_plan(d, Ld, out, false, 16, -(1000 + wd));
         if (derr.rfind("rows-too-long-for-dense", 0) == 0) {
             // (the implicitly eliminated Neumann levels of 3-D hierarchies: up to ~200 entries per row)
-            const int wl = waves >= 6 ? 6 : 4;  // wavefront counts the long-row kernels exist for
-            derr = build_level_plan(d, 16, out, false, 16, -wl, true);
+            const int wl = wd >= 6 ? 6 : 4;  // wavefront counts the long-row kernels exist for
+            derr = build_level_plan(d, 16, out, false, 16, -(1000 + wl), true);
         }
         if (derr.rfind("rows-too-long-for-dense", 0) != 0) return derr;
         waves = 1;
     }
-    const int dense_waves = waves < -1 ? -waves : 0;
+    const int dense_waves = waves <= -1000 ? -waves - 1000 : 0;
     const int n = d.n;
     CsrView A{d.a_size, d.a_size, d.rowptr, d.col, d.val};
     std::vector<int32_t> pt_tile;

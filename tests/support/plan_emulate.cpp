@@ -233,7 +233,7 @@ void *emu_level_create(const mmg_level_desc *d)
     const int L = d->lanes_per_row > 0 ? d->lanes_per_row : 4;
     std::string err = check_multiplier(*d, &e->mult_row);
     if (err.empty()) err = build_boundary_lists(*d, &e->bl);
-    if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits, d->waves_per_tile > 1 ? d->waves_per_tile : 1);
+    if (err.empty()) err = build_level_plan(*d, L, &e->A, false, g_slot_bits, (d->waves_per_tile > 1 || d->waves_per_tile == -1) ? d->waves_per_tile : 1);
     if (err.empty() && !e->bl.neu_rows.empty()) {
         CsrView A{d->a_size, d->a_size, d->rowptr, d->col, d->val};
         err = build_gather_plan_host(A, e->bl.neu_rows, L, 64, true, true, true, -1, &e->B);
@@ -257,7 +257,11 @@ void emu_level_info(void *h, int *out6)
 }
 
 int emu_level_slot_bits(void *h) { return static_cast<Emu *>(h)->A.slot_bits; }
-int emu_level_waves(void *h) { return static_cast<Emu *>(h)->A.dense ? static_cast<Emu *>(h)->A.waves : 0; }
+int emu_level_waves(void *h)
+{
+    const Emu *e = static_cast<Emu *>(h);
+    return e->A.dense ? (e->A.waves == 1 ? -1 : e->A.waves) : 0;  // -1: dense layout, one wavefront per tile
+}
 int emu_level_dense_long(void *h) { return static_cast<Emu *>(h)->A.dense_long ? 1 : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
