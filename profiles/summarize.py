@@ -71,6 +71,34 @@ def main():
             spl = rl.get("sweeps_in_launches", rl["launches"]) / rl["launches"]
             lines.append(f"algorithmic bytes per sweep: {alg_sweep:.1f} MB; PMC traffic {traffic:.1f} MB per launch of "
                          f"{spl:.0f} sweeps = {traffic/spl:.1f} MB per sweep (ratio {traffic/spl/alg_sweep:.2f})")
+    # ---- the dominant kernel split by sweeps per launch (kernel trace, one row per dispatch) ----
+    # The fine-level sweep kernel is launched with 16 fused sweeps by the timed loop and with `iters` = 5 by every
+    # smoothing call of the V-cycle legs; the aggregate statistics above mix the two.  Each dispatch is classified by
+    # round(duration / us_per_sweep of the bench line); per class: launches, average duration, us per sweep and the
+    # roofline fraction that goes with it -- `roofline.frac` (16) and `roofline.frac_in_vcycle` (5) of the bench line.
+    tr = glob.glob(os.path.join(stats_dir, "**", "*_kernel_trace.csv"), recursive=True)
+    if bench and tr:
+        rl = bench["roofline"]
+        cfg = bench["config"]
+        per_sweep_us = rl.get("us_per_sweep", rl["avg_launch_us"])
+        alg_sweep_b = cfg["interior_points_per_gpu"] * rl["algorithmic_bytes_per_row"]
+        groups = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr[0])):
+            if "sweep_persistent_kernel" not in r["Kernel_Name"]:
+                continue
+            us = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
+            k = int(round(us / per_sweep_us))
+            if k >= 1 and us > 0.5 * per_sweep_us:      # (launches of the same template on coarser levels are shorter)
+                groups[k].append(us)
+        if groups:
+            lines += ["", "| `sweep_persistent_kernel` launches carrying | launches | avg us per launch | us per sweep | % of 8 TB/s |",
+                      "|---|---|---|---|---|"]
+            for k in sorted(groups, reverse=True):
+                v = groups[k]
+                if len(v) < 2:
+                    continue
+                avg = sum(v) / len(v)
+                lines.append(f"| {k} sweeps | {len(v)} | {avg:.1f} | {avg / k:.1f} | {alg_sweep_b * k / (avg * 1e-6) / 8e12 * 100:.1f} |")
     if bench and traffic:
         # what bench.py reports as roofline.traffic (only for a run of the same shape)
         json.dump({"source": f"profiles/{tag}_summary.md", "kernel": rl["kernel"], "bytes_per_launch": traffic * 1e6,
