@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1, help="0: issue every launch of the cycle body directly (A/B of the HIP graph)")
     ap.add_argument("--waves", type=int, default=0, help="waves_per_tile option: 0 automatic, 1 packed stream everywhere (A/B)")
     ap.add_argument("--point-colouring", type=int, default=-1, help="-1 automatic (2-D: 2, 3-D: 1); 0 / 1: point colours inside the tiles; 2: lexicographic SWEEP order inside the tiles")
+    ap.add_argument("--dense-xtra", type=int, default=1, help="0: 16 x 4 entries per dense row slot instead of 16 x 3 + 1 (A/B)")
     ap.add_argument("--dense-single", type=int, default=1, help="0: keep multi-wavefront rounds on sweep-ordered levels (A/B)")
     ap.add_argument("--tile-order", type=int, default=0, help="1: tiles in lexicographic sweep order instead of tile colours")
     ap.add_argument("--tile", type=int, default=0, help="points per tile (0: automatic)")
@@ -44,6 +45,7 @@ def main():
     _capi.set_option("vcycle_graph", a.graph)
     _capi.set_option("waves_per_tile", a.waves)
     _capi.set_option("dense_single", a.dense_single)
+    _capi.set_option("dense_xtra", a.dense_xtra)
     _host.set_option("point_colouring", a.point_colouring)
     _host.set_option("tile_order", a.tile_order)
     t0 = time.perf_counter()

@@ -218,6 +218,7 @@ struct PlanGpu {
         dev.L = P.L;
         dev.dense = P.dense ? 1 : 0;
         dev.dense_long = P.dense_long ? 1 : 0;
+        dev.dense_xtra = P.dense_xtra ? 1 : 0;
         dev.waves = P.waves;
         max_levels = 0;
         for (const TileDesc &t : P.tiles) max_levels = std::max(max_levels, (int)t.n_levels);
@@ -1033,6 +1034,7 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "debug_spin_bound") == 0) { g_spin_bound = value < 0 ? (1 << 22) : value; return MMG_OK; }
     if (std::strcmp(name, "debug_fail_graph") == 0) { g_debug_fail_graph = value; return MMG_OK; }
     if (std::strcmp(name, "dense_single") == 0) { g_dense_single = value; return MMG_OK; }
+    if (std::strcmp(name, "dense_xtra") == 0) { mmg::g_dense_xtra_enabled = value; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -15,6 +15,7 @@ struct PlanDev {
     int L = 4;
     int dense = 0;       // Plan::dense: fixed-shape groups, `waves` wavefronts per tile (kernels_mw.hip)
     int dense_long = 0;  // Plan::dense_long: rows may span several row slots of a group
+    int dense_xtra = 0;  // Plan::dense_xtra: one extra entry per row (value after the slot section, slot in RowMeta::flags >> 1)
     int waves = 1;
     int slot_bits = 16;  // Plan::slot_bits
     int n_tiles = 0;

@@ -44,24 +44,27 @@ struct DenseRegs {
     unsigned s[kSlotWords];              // 16-bit LDS slots, two per dword
     uint4 info;                          // RowInfo of the lane's row: gid | self, flags | 1 / diag
     double diag;                         // RESID only
+    double xval;                         // Plan::dense_xtra: the row's extra entry (its slot: flags >> 1)
 };
 
-template <int L, int P>
+template <int L, int P, bool X = false>
 struct DenseShape {  // plan.hpp: dense_off_* / dense_group_bytes
     static constexpr int G = 64 / L;
     static constexpr int kOffDiag = 16 * G;
     static constexpr int kOffVal = 24 * G;
     static constexpr int kOffSlot = kOffVal + P * 512;
     static constexpr int kSlotBytes = 4 * DenseRegs<P>::kSlotWords;
-    static constexpr int kBytes = kOffSlot + kSlotBytes * 64;
+    static constexpr int kOffX = kOffSlot + kSlotBytes * 64;
+    static constexpr int kBytes = kOffX + (X ? 8 * G : 0);
 };
 
-template <int L, int P, int MODE>
+template <int L, int P, int MODE, bool X = false>
 __device__ __forceinline__ void issue_dense(const unsigned char *gp, int lane, DenseRegs<P> &r)
 {
-    using S = DenseShape<L, P>;
+    using S = DenseShape<L, P, X>;
     using R = DenseRegs<P>;
     r.info = reinterpret_cast<const uint4 *>(gp)[lane / L];
+    if (X) r.xval = reinterpret_cast<const double *>(gp + S::kOffX)[lane / L];
     if (MODE == MODE_RESID) r.diag = reinterpret_cast<const double *>(gp + S::kOffDiag)[lane / L];
 #pragma unroll
     for (int h = 0; h < R::kPairs; ++h) r.v[h] = reinterpret_cast<const double2 *>(gp + S::kOffVal + h * 1024)[lane];
@@ -93,10 +96,10 @@ __device__ __forceinline__ unsigned dense_slot(const DenseRegs<P> &g, int q)
 }
 
 // LDS: xs[n_slots] | bs[n_own] | red[NW] (cross-wavefront partial sums)
-template <int L, int MODE, int P, bool SC1, int NW, int DEPTH, bool LONG = false>
+template <int L, int MODE, int P, bool SC1, int NW, int DEPTH, bool LONG = false, bool X = false>
 __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int tile, unsigned char *smem, const double lam)
 {
-    using S = DenseShape<L, P>;
+    using S = DenseShape<L, P, X>;
     constexpr int NT = 64 * NW;
     constexpr bool kInPlace = MODE == MODE_SOR;
     double *xs = reinterpret_cast<double *>(smem);
@@ -121,7 +124,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     if (n_rounds > 0) {
 #pragma unroll
         for (int j = 0; j < DEPTH - 1; ++j) {
-            issue_dense<L, P, MODE>(gp0 + (size_t)ri * RB, lane, r[j]);
+            issue_dense<L, P, MODE, X>(gp0 + (size_t)ri * RB, lane, r[j]);
             ri += (ri + 1 < n_rounds) ? 1 : 0;
         }
     }
@@ -177,6 +180,8 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         double xv[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) xv[q] = xs[dense_slot<P>(g, q)];
+        double xx = 0.0;
+        if (X) xx = xs[g.info.y >> 17];     // the extra entry's column (empty: the zero slot)
         __builtin_amdgcn_sched_barrier(0);  // every gather in flight before the first FMA
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -186,6 +191,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         }
         if (P & 1) acc0 = fma(g.vlast, xv[P - 1], acc0);
         double acc = row_sum<L>(acc0 + acc1);
+        if (X) acc = fma(g.xval, xx, acc);  // (used by the row's first lane only)
         const uint32_t gid = g.info.x;
         if (LONG) {
             // Plan::dense_long: a row may continue in the row slots after its own (gid == kNoRow, self == kContSlot);
@@ -204,7 +210,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
             }
         }
         if (sub == 0 && gid != kNoRow) {
-            const uint32_t self = g.info.y & 0xffffu, flags = g.info.y >> 16;
+            const uint32_t self = g.info.y & 0xffffu, flags = g.info.y >> 16;  // (dense_xtra: bits 1..15 hold the extra slot)
             const double invd = __longlong_as_double(((unsigned long long)g.info.w << 32) | g.info.z);
             if (MODE == MODE_SOR) {
                 double xi = bs[self] - acc;
@@ -231,7 +237,7 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     for (int t = 0; t < n_main; ++t) {
 #pragma unroll
         for (int j = 0; j < DEPTH; ++j) {
-            issue_dense<L, P, MODE>(gp0 + (size_t)ri * RB, lane, r[(j + DEPTH - 1) % DEPTH]);
+            issue_dense<L, P, MODE, X>(gp0 + (size_t)ri * RB, lane, r[(j + DEPTH - 1) % DEPTH]);
             ri += (ri + 1 < n_rounds) ? 1 : 0;
             finish(r[j]);
             // the x values written in this round are read by the next one, by any wavefront
@@ -307,7 +313,7 @@ template <int P>
 constexpr int kDepthMw = P <= 4 ? 4 : 3;
 
 // one launch per phase: one workgroup of NW wavefronts per tile
-template <int L, int MODE, int P, int NW, bool LONG = false>
+template <int L, int MODE, int P, int NW, bool LONG = false, bool X = false>
 __global__ __launch_bounds__(64 * NW) void tile_kernel_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel_mw(TileArgs a)
     const int tile = a.tile_list ? a.tile_list[idx] : idx;
     double lam = 0.0;
     if (a.lambda) lam = *a.lambda;
-    process_tile_mw<L, MODE, P, false, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
+    process_tile_mw<L, MODE, P, false, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
 }
 
 // Workgroup-wide broadcast of a value that wavefront 0 holds (the same in all its lanes).
@@ -340,7 +346,7 @@ __device__ __forceinline__ unsigned wg_bcast(unsigned v, bool wave0, unsigned *s
 
 // all tiles of a tiny level resident at once (grid <= resident workgroups): workgroup b owns tile b for every
 // phase and every fused sweep of the launch; protocol of sweep_resident_kernel (kernels.hip)
-template <int L, int P, int NW, bool LONG = false>
+template <int L, int P, int NW, bool LONG = false, bool X = false>
 __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<2>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have; LDS free for the next sweep
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
 
 // dependency-driven single launch: resident workgroups draw tiles from the ticket counter in phase order;
 // protocol of sweep_persistent_kernel (kernels.hip)
-template <int L, int P, int NW, bool LONG = false>
+template <int L, int P, int NW, bool LONG = false, bool X = false>
 __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<8>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
 
 enum MwKernel { MW_TILE_SOR, MW_TILE_RESID, MW_RESIDENT, MW_PERSISTENT };
 
-template <int L, int P, int NW, bool LONG = false>
+template <int L, int P, int NW, bool LONG = false, bool X = false>
 hipError_t launch_mw_LPN(MwKernel k, const TileArgs &a, int workers, hipStream_t s, int *occ)
 {
     const size_t lds = a.p.lds_bytes;
@@ -406,20 +412,20 @@ hipError_t launch_mw_LPN(MwKernel k, const TileArgs &a, int workers, hipStream_t
     switch (k) {
     case MW_TILE_SOR: {
         const int per = (a.n_list + 7) / 8;
-        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_SOR, P, NW, LONG>), dim3((unsigned)(per * 8)), block, lds, s, a);
+        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_SOR, P, NW, LONG, X>), dim3((unsigned)(per * 8)), block, lds, s, a);
         break;
     }
     case MW_TILE_RESID: {
         const int per = (a.n_list + 7) / 8;
-        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_RESID, P, NW, LONG>), dim3((unsigned)(per * 8)), block, lds, s, a);
+        hipLaunchKernelGGL((tile_kernel_mw<L, MODE_RESID, P, NW, LONG, X>), dim3((unsigned)(per * 8)), block, lds, s, a);
         break;
     }
     case MW_RESIDENT:
-        hipLaunchKernelGGL((sweep_resident_mw<L, P, NW, LONG>), dim3((unsigned)a.n_list), block, lds, s, a);
+        hipLaunchKernelGGL((sweep_resident_mw<L, P, NW, LONG, X>), dim3((unsigned)a.n_list), block, lds, s, a);
         break;
     case MW_PERSISTENT:
-        if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, sweep_persistent_mw<L, P, NW, LONG>, 64 * NW, lds);
-        hipLaunchKernelGGL((sweep_persistent_mw<L, P, NW, LONG>), dim3((unsigned)workers), block, lds, s, a);
+        if (occ) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, sweep_persistent_mw<L, P, NW, LONG, X>, 64 * NW, lds);
+        hipLaunchKernelGGL((sweep_persistent_mw<L, P, NW, LONG, X>), dim3((unsigned)workers), block, lds, s, a);
         break;
     }
     return hipGetLastError();
@@ -466,6 +472,18 @@ hipError_t launch_mw(MwKernel k, const TileArgs &a, int workers, hipStream_t s, 
         if (a.p.L != 16 || a.p.max_plen != 4) return hipErrorInvalidValue;
         if (a.p.waves == 4) return launch_mw_LPN<16, 4, 4, true>(k, a, workers, s, occ);
         if (a.p.waves == 6) return launch_mw_LPN<16, 4, 6, true>(k, a, workers, s, occ);
+        return hipErrorInvalidValue;
+    }
+    if (a.p.dense_xtra) {  // 16 lanes x 3 entries + the extra plane: the 3-D K = 50 shape
+        if (a.p.L != 16 || a.p.max_plen != 3) return hipErrorInvalidValue;
+        switch (a.p.waves) {
+        case 2: return launch_mw_LPN<16, 3, 2, false, true>(k, a, workers, s, occ);
+        case 3: return launch_mw_LPN<16, 3, 3, false, true>(k, a, workers, s, occ);
+        case 4: return launch_mw_LPN<16, 3, 4, false, true>(k, a, workers, s, occ);
+        case 6: return launch_mw_LPN<16, 3, 6, false, true>(k, a, workers, s, occ);
+        case 8: return launch_mw_LPN<16, 3, 8, false, true>(k, a, workers, s, occ);
+        case 12: return launch_mw_LPN<16, 3, 12, false, true>(k, a, workers, s, occ);
+        }
         return hipErrorInvalidValue;
     }
     switch (a.p.L) {

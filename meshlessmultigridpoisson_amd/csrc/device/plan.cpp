@@ -26,6 +26,8 @@
 #include <sched.h>
 
 namespace mmg {
+int g_dense_xtra_enabled = 1;  // plan.hpp: mmg_set_option("dense_xtra", 0) keeps 16 x 4 entries per row slot (A/B)
+
 
 int host_threads()
 {
@@ -317,12 +319,13 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
             if (r >= (int)fill.size()) fill.resize((size_t)r + 1, 0);
             ++fill[r];
             round_of[k] = r;
-            if ((int)((ent(k).size() + L - 1) / L) > P) { tb.err = "rows-too-long-for-dense"; return; }
+            if ((int)ent(k).size() > P * L + (s.dense_xtra ? 1 : 0)) { tb.err = "rows-too-long-for-dense"; return; }
         }
         const int n_rounds = (int)fill.size();
         std::vector<std::vector<int32_t>> by_round(n_rounds);
         for (int k = 0; k < m; ++k) by_round[round_of[k]].push_back(k);
-        const size_t GB = dense_group_bytes(L, P);
+        const bool XT = s.dense_xtra;
+        const size_t GB = dense_group_bytes(L, P, XT);
         tb.blob.assign((size_t)n_rounds * NW * GB, 0);
         uint8_t *B = tb.blob.data();
         for (int r = 0; r < n_rounds; ++r) {
@@ -331,7 +334,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                 uint8_t *gp = B + ((size_t)r * NW + w) * GB;
                 // everything empty first: no row, value 0, zero slot
                 for (int i = 0; i < G; ++i) {
-                    RowInfo ri{RowMeta{kNoRow, kNoSlot, 0}, 1.0};
+                    RowInfo ri{RowMeta{kNoRow, kNoSlot, (uint16_t)(XT ? (zero_slot << 1) : 0)}, 1.0};
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
                     const double one = 1.0;
                     std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &one, 8);
@@ -344,10 +347,18 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     const int k = rows[idx];
                     RowInfo ri{meta[k], 1.0 / diag[k]};
                     if (!s.extract_diag) ri.inv_diag = 1.0;
+                    const auto e = ent(k);
+                    size_t n_lane = e.size();      // entries that go to the lanes
+                    if (XT) {                      // the extra plane: entry P * L of the row, if it has one
+                        uint16_t xs = zero_slot;
+                        double xv = 0.0;
+                        if (e.size() > (size_t)P * L) { n_lane = (size_t)P * L; xs = e[n_lane].slot; xv = e[n_lane].val; }
+                        ri.meta.flags = (uint16_t)((ri.meta.flags & 1u) | ((uint32_t)xs << 1));
+                        std::memcpy(gp + dense_off_x(L, P) + (size_t)8 * i, &xv, 8);
+                    }
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
                     std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &diag[k], 8);
-                    const auto e = ent(k);
-                    for (size_t x = 0; x < e.size(); ++x) {
+                    for (size_t x = 0; x < n_lane; ++x) {
                         const int q = (int)(x / L), lane = (int)(i * L + x % L);
                         std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
                         std::memcpy(gp + dense_slot_off(L, P, q, lane), &e[x].slot, 2);
@@ -458,6 +469,9 @@ std::string build_plan(const PlanSpec &s, Plan *out)
         } else {
             sd.dense_plen = dense_plen_class(need);
             if (!sd.dense_plen) return "rows-too-long-for-dense";
+            // rows of exactly 3 * 16 + 1 entries (3-D K = 50: 49 off-diagonal): 3 entries per lane + the extra plane
+            const int maxent = std::max(1, maxlen - drop);
+            if (L == 16 && sd.dense_plen == 4 && maxent <= 3 * L + 1 && g_dense_xtra_enabled) { sd.dense_plen = 3; sd.dense_xtra = true; }
         }
     }
 
@@ -515,6 +529,7 @@ std::string build_plan(const PlanSpec &s, Plan *out)
     P.waves = s.dense_waves > 0 ? s.dense_waves : 1;
     P.dense_plen = sd.dense_plen;
     P.dense_long = s.dense_waves > 0 && s.dense_long;
+    P.dense_xtra = s.dense_waves > 0 && sd.dense_xtra;
     P.slot_bits = s.slot_bits == 12 ? 12 : 16;
     P.n_tiles = s.n_tiles;
     P.tiles.resize(s.n_tiles);

@@ -162,7 +162,14 @@ inline size_t dense_slot_bytes(int plen) { return plen <= 4 ? 8 : (plen <= 6 ? 1
 inline size_t dense_off_diag(int L) { return (size_t)16 * (64 / L); }
 inline size_t dense_off_val(int L) { return (size_t)24 * (64 / L); }
 inline size_t dense_off_slot(int L, int plen) { return dense_off_val(L) + (size_t)plen * 512; }
-inline size_t dense_group_bytes(int L, int plen) { return dense_off_slot(L, plen) + dense_slot_bytes(plen) * 64; }
+// Plan::dense_xtra: ONE more entry per row behind the plen * L of the lanes -- its value in xval[64/L] after the slot
+// section, its LDS slot in bits 1..15 of RowMeta::flags (bit 0 stays the multiplier flag).  A 3-D K = 50 row has 49
+// off-diagonal entries: 16 lanes x 3 entries + 1 instead of 16 x 4 with 15 empty slots (552 instead of 664 B per row).
+inline size_t dense_off_x(int L, int plen) { return dense_off_slot(L, plen) + dense_slot_bytes(plen) * 64; }
+inline size_t dense_group_bytes(int L, int plen, bool xtra = false)
+{
+    return dense_off_x(L, plen) + (xtra ? (size_t)8 * (64 / L) : 0);
+}
 // byte offset (from the group base) of value / slot q of a lane
 inline size_t dense_val_off(int L, int plen, int q, int lane)
 {
@@ -180,6 +187,7 @@ struct Plan {
     bool dense = false;                // dense multi-wavefront layout (see the header comment)
     int waves = 1;                     // wavefronts per tile (dense plans: groups per round)
     int dense_plen = 0;                // entries per lane of every group (dense plans: one of kDensePlens)
+    bool dense_xtra = false;           // one extra entry per row (dense_off_x; kernels: L = 16, dense_plen = 3)
     bool dense_long = false;           // a row may span several consecutive row slots of its group (kContSlot): the rows
                                        // of an implicitly eliminated Neumann level in 3-D hold up to ~200 entries
     int slot_bits = 16;                // 16, or 12 when every tile has <= 4096 LDS slots (level plans, L = 2/4)
@@ -244,6 +252,7 @@ struct PlanSpec {
     // stored entries; 16-bit slots); fails with "rows-too-long-for-dense" otherwise
     int dense_waves = 0;
     int dense_plen = 0;         // set by build_plan
+    bool dense_xtra = false;    // set by build_plan: rows of dense_plen * L + 1 entries, the last one in the extra plane
     bool dense_long = false;    // rows longer than dense_plen * L entries take several row slots (16 lanes per row,
                                 // 4 entries per lane, at most 4 slots = 256 entries) instead of failing
 };
@@ -254,5 +263,7 @@ struct PlanSpec {
 std::string build_plan(const PlanSpec &spec, Plan *out);
 
 std::vector<int64_t> uniform_tile_ptr(int64_t n_rows, int rows_per_tile);
+
+extern int g_dense_xtra_enabled;  // 1: dense plans of 16 lanes per row use the extra entry plane when the rows have 49 entries
 
 }  // namespace mmg

@@ -347,6 +347,7 @@ double Grid::default_mult_row = 0.0;
 int Grid::default_device_setup = -1;
 int Grid::default_point_colouring = -1;
 int Grid::default_tile_order = 0;
+int Grid::default_sweep_min_points = 0;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,
                             const vector<int> &ops, mmgh::RawVec<int> &nbr, mmgh::RawVec<double> &w, bool by_column)

@@ -66,6 +66,7 @@ public:
                                  // 1 smallest-last + iterated greedy colours, 2 lexicographic SWEEP order (no colour classes)
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring"); 2: lexicographic SWEEP order inside the tiles
     int tile_order_ = 0;         // mc_order_points, order of the tiles: 0 by tile colour (4 / 8 phases), 1 lexicographic sweep over the tiles
+    static int default_sweep_min_points;  // mmgh_set_option "sweep_min_points": automatic point order uses colour classes below this size
     static int default_tile_order;       // mmgh_set_option "tile_order"
     int setup_threads_ = 0;      // 0 = hardware concurrency
     // Dense stencil solves of the setup (laplaceWeights / pointInterpWeights / deriv*_weights):

@@ -334,7 +334,8 @@ void Grid::mc_order_points(int tile_points)
     // automatic (-1): 2-D clouds get the sweep order (the reference's 2-D parameter sets -- omega 1.4, fine polyDeg
     // 4-6 -- diverge under colour classes and contract under a sweep); 3-D clouds keep the colour
     // classes (K = 50 Dirichlet hierarchies contract alike under both, the sweep order costs 4x there)
-    const int point_order = point_colouring_ >= 0 ? point_colouring_ : (dim_ >= 3 ? 1 : 2);
+    int point_order = point_colouring_ >= 0 ? point_colouring_ : (dim_ >= 3 ? 1 : 2);
+    if (point_colouring_ < 0 && point_order == 2 && n < default_sweep_min_points) point_order = 1;  // experiment: colours on small grids
     par_for(nt, nth, [&](int t) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
         vector<vector<int>> ladj((size_t)m);

@@ -88,6 +88,10 @@ def main():
                 continue
             us = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3
             k = int(round(us / per_sweep_us))
+            for e in (16, 5):                            # the two kinds the bench run issues: a cold 5-sweep launch
+                if abs(us / (e * per_sweep_us) - 1.0) < 0.25:   # 12 % slow is still a 5-sweep launch, not a "6-sweep" one
+                    k = e
+                    break
             if k >= 1 and us > 0.5 * per_sweep_us:      # (launches of the same template on coarser levels are shorter)
                 groups[k].append(us)
         if groups:

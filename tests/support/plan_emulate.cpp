@@ -39,7 +39,7 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
                     double omega, double lam, double *abs_acc)
 {
     const int L = P.L, G = 64 / L, NW = P.waves, PL = P.dense_plen;
-    const size_t GB = dense_group_bytes(L, PL);
+    const size_t GB = dense_group_bytes(L, PL, P.dense_xtra);
     const size_t off_diag = dense_off_diag(L);
     const uint8_t *base = P.stream.data() + td.stream_off;
     struct Upd { RowMeta m; double acc, d, invd; };
@@ -83,6 +83,13 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
                 std::memcpy(&d, gp + off_diag + (size_t)8 * i, 8);
                 double acc = slot_sum[i];
                 for (int j = i + 1; j < G && infos[j].meta.gid == kNoRow && infos[j].meta.self == kContSlot; ++j) acc += slot_sum[j];
+                if (P.dense_xtra) {  // the row's extra entry: value after the slot section, slot in flags >> 1
+                    double xv;
+                    std::memcpy(&xv, gp + dense_off_x(L, PL) + (size_t)8 * i, 8);
+                    const uint32_t xsl = (uint32_t)ri.meta.flags >> 1;
+                    if (xsl >= xs.size()) { g_err = "extra entry slot outside the tile"; continue; }
+                    acc = std::fma(xv, xs[xsl], acc);
+                }
                 upd.push_back(Upd{ri.meta, acc, d, ri.inv_diag});
             }
             if (seen != (int)(h & 0xffu)) g_err = "dense group head disagrees with its row slots";
@@ -263,6 +270,7 @@ int emu_level_waves(void *h)
     return e->A.dense ? (e->A.waves == 1 ? -1 : e->A.waves) : 0;  // -1: dense layout, one wavefront per tile
 }
 int emu_level_dense_long(void *h) { return static_cast<Emu *>(h)->A.dense_long ? 1 : 0; }
+int emu_level_dense_xtra(void *h) { return static_cast<Emu *>(h)->A.dense_xtra ? 1 : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
 

@@ -201,3 +201,24 @@ def test_packed_plans_of_high_degree_neumann_levels_match_oracle(host, deg, wave
     assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(ro).max())
     assert abs(nrm - np.abs(ro).sum()) <= 1e-10 * np.abs(ro).sum()
     assert e.L.emu_level_nnz(e.h) > 0
+
+
+@pytest.mark.parametrize("deg", [4, 5, 6])
+def test_host_neumann_assembly_matches_numpy_oracle_at_live_degrees(host, deg):
+    """The host C++ setup (what every GPU test builds its operators with) against the independent numpy restatement
+    (oracle/setup_oracle.py) at the reference's live degrees, Neumann, Gmsh-like cloud, the reference's RCM order:
+    identical points, flags, sparsity (K = 37 / 52 / 70 stencils + multiplier + elimination fill), boundary lists;
+    values to 1e-6 of the matrix scale (two full-pivot LU codes on the ill-conditioned degree-6 saddle systems)."""
+    from oracle import setup_oracle as so
+    pts = host.quasi_uniform_square_cloud(13)
+    og = so.gen_grid_neumann_square(pts, so.make_props(deg))
+    hg = host.Grid.create_square(pts, deg, kind=host.KIND_NEUMANN, ordering=host.ORDER_RCM)
+    rowptr, col, val = hg.csr()
+    orp, ocol, oval = og.csr
+    xyz, flags = hg.points()
+    assert np.array_equal(xyz, og.points) and np.array_equal(flags, og.bcflags)
+    assert np.array_equal(rowptr, orp) and np.array_equal(col, ocol)
+    assert np.abs(val - oval).max() <= 1e-6 * np.abs(oval).max()
+    _bt, _bp, bpts, _bv = hg.boundaries()
+    assert np.array_equal(bpts, og.boundary_arrays()[2])
+    assert np.abs(hg.source() - og.source).max() <= 1e-5 * np.abs(og.source).max()
