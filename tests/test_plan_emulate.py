@@ -238,3 +238,65 @@ def test_dense_groups_with_rows_over_several_row_slots():
         assert H.rel_err(emu.x, lv.x) < 1e-12, waves
         r_e, _nrm = emu.residual()
         assert H.rel_err(r_e, lv.residual()) < 1e-11, waves
+
+
+def test_sweep_ordered_level_dense_layout_with_one_wavefront_per_tile():
+    """Round 3: a 2-D level ordered by Grid::mc_order_points as a lexicographic SWEEP inside its tiles (point order 2,
+    the order in which the reference's over-relaxed cycle converges) has ~4 uncoupled rows per dependency level.  The
+    dense layout with ONE wavefront per tile (waves_per_tile = -1: rounds of a single group) streams half the bytes of
+    rounds of two groups, and sweeps / residual are the oracle's (interpreter: all rows of a round read first)."""
+    import ctypes
+    from meshlessmultigridpoisson_amd import _host as host
+    host.set_option("point_colouring", 2)
+    try:
+        g = host.Grid.create_square(host.quasi_uniform_square_cloud(61), 4, kind=host.KIND_DIRICHLET, ordering=host.ORDER_MC,
+                                    tile_points=256)
+    finally:
+        host.set_option("point_colouring", -1)
+    la = g.level_arrays()
+    rng = np.random.default_rng(4)
+    la["x0"] = rng.standard_normal(la["a_size"])
+    lib = H.emu_lib()
+    lib.emu_level_waves.argtypes = [ctypes.c_void_p]
+    o = H.oracle_level(la)
+    o.sor_sweeps(2)
+    ro = o.residual()
+    nbytes = {}
+    for waves in (-1, 2):
+        e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=8, waves_per_tile=waves)
+        assert lib.emu_level_waves(e.h) == waves
+        e.sweeps(2)
+        assert H.rel_err(e.x, o.x) < 1e-12
+        r, _nrm = e.residual()
+        assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(ro).max())
+        nbytes[waves] = lib.emu_level_stream_bytes(e.h)
+        # the sweep order shows as a long dependency chain: several times the ~20 colour classes of a coloured tile
+        assert e.info()["n_groups"] / e.info()["n_tiles"] > 40 * (2 if waves == 2 else 1)
+    assert nbytes[-1] < 0.6 * nbytes[2]
+
+
+def test_dense_layout_extra_entry_plane_for_3d_stencils():
+    """Round 3: rows of 49 off-diagonal entries (3-D, K = 50) in dense groups of 16 lanes x 3 entries + ONE extra entry
+    per row (value after the slot section, slot in RowMeta::flags >> 1) instead of 16 x 4 with 15 empty slots.
+    mmg_set_option("dense_xtra", 0) keeps the old shape; both reproduce the oracle."""
+    import ctypes
+    from meshlessmultigridpoisson_amd import _host as host
+    g = host.Grid.create_square(host.box_cloud(16, 3, seed=3), 3, dim=3, kind=host.KIND_DIRICHLET, ordering=host.ORDER_MC,
+                                tile_points=256)
+    la = g.level_arrays()
+    assert int(np.diff(la["rowptr"]).max()) == 50
+    rng = np.random.default_rng(8)
+    la["x0"] = rng.standard_normal(la["a_size"])
+    o = H.oracle_level(la)
+    o.sor_sweeps(2)
+    ro = o.residual()
+    lib = H.emu_lib()
+    lib.emu_level_dense_xtra.argtypes = [ctypes.c_void_p]
+    e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=16, waves_per_tile=4)
+    assert lib.emu_level_dense_xtra(e.h) == 1
+    e.sweeps(2)
+    assert H.rel_err(e.x, o.x) < 1e-12
+    r, nrm = e.residual()
+    assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(ro).max())
+    assert abs(nrm - np.abs(ro).sum()) <= 1e-10 * np.abs(ro).sum()
+    assert lib.emu_last_error() in (b"", None)
