@@ -471,7 +471,12 @@ std::string build_plan(const PlanSpec &s, Plan *out)
             if (!sd.dense_plen) return "rows-too-long-for-dense";
             // rows of exactly 3 * 16 + 1 entries (3-D K = 50: 49 off-diagonal): 3 entries per lane + the extra plane
             const int maxent = std::max(1, maxlen - drop);
-            if (L == 16 && sd.dense_plen == 4 && maxent <= 3 * L + 1 && g_dense_xtra_enabled) { sd.dense_plen = 3; sd.dense_xtra = true; }
+            // Only where bytes matter: measured on the same box, 150^3: 423 vs 446 us per sweep (60 vs 57 % of 8 TB/s),
+            // 108^3: 198 vs 202 us (chain-bound, no gain), 216^3 4-level V-cycle 16.70 vs 16.62 ms (the chain-bound
+            // 54^3 / 27^3 levels pay for the extra gather) -- g_dense_xtra_enabled: 1 = plans of at least 2e6 rows,
+            // 2 = always (tests), 0 = never.
+            const bool big = s.n_rows >= 2000000 || g_dense_xtra_enabled >= 2;
+            if (L == 16 && sd.dense_plen == 4 && maxent <= 3 * L + 1 && g_dense_xtra_enabled && big) { sd.dense_plen = 3; sd.dense_xtra = true; }
         }
     }
 

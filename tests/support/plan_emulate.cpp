@@ -270,6 +270,7 @@ int emu_level_waves(void *h)
     return e->A.dense ? (e->A.waves == 1 ? -1 : e->A.waves) : 0;  // -1: dense layout, one wavefront per tile
 }
 int emu_level_dense_long(void *h) { return static_cast<Emu *>(h)->A.dense_long ? 1 : 0; }
+void emu_set_dense_xtra(int v) { mmg::g_dense_xtra_enabled = v; }
 int emu_level_dense_xtra(void *h) { return static_cast<Emu *>(h)->A.dense_xtra ? 1 : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }

@@ -292,7 +292,11 @@ def test_dense_layout_extra_entry_plane_for_3d_stencils():
     ro = o.residual()
     lib = H.emu_lib()
     lib.emu_level_dense_xtra.argtypes = [ctypes.c_void_p]
-    e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=16, waves_per_tile=4)
+    lib.emu_set_dense_xtra(2)      # 1 (default): only plans of >= 2e6 rows, where the bytes matter; 2: always
+    try:
+        e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=16, waves_per_tile=4)
+    finally:
+        lib.emu_set_dense_xtra(1)
     assert lib.emu_level_dense_xtra(e.h) == 1
     e.sweeps(2)
     assert H.rel_err(e.x, o.x) < 1e-12

@@ -9,11 +9,11 @@ ns = int(sys.argv[1])
 _host.set_option("device_setup", 1)
 pts = _host.box_cloud(ns, 3, seed=12345)
 out = []
-for xtra in (1, 0):
+for xtra in (2, 0):
     for w in [int(v) for v in sys.argv[2:]] or [0]:
         _capi.set_option("dense_xtra", xtra)
         _capi.set_option("waves_per_tile", w)
-        tile = _capi.auto_tile_points(ns ** 3, 3, 50, 0, 256, 163840) if w != 1 else 0
+        tile = int(os.environ.get("TILE", "0")) or (_capi.auto_tile_points(ns ** 3, 3, 50, 0, 256, 163840) if w != 1 else 0)
         g = _host.Grid.create_square(pts, 3, dim=3, kind=_host.KIND_DIRICHLET, ordering=_host.ORDER_MC, tile_points=tile)
         sz = g.sizes()
         lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
