@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--point-colouring", type=int, default=-1, help="-1 automatic (2-D: 2, 3-D: 1); 0 / 1: point colours inside the tiles; 2: lexicographic SWEEP order inside the tiles")
     ap.add_argument("--dense-xtra", type=int, default=1, help="0: 16 x 4 entries per dense row slot instead of 16 x 3 + 1 (A/B)")
     ap.add_argument("--dense-single", type=int, default=1, help="0: keep multi-wavefront rounds on sweep-ordered levels (A/B)")
-    ap.add_argument("--tile-order", type=int, default=0, help="1: tiles in lexicographic sweep order instead of tile colours")
+    ap.add_argument("--tile-order", type=int, default=-1, help="-1 automatic (2-D Neumann: 1); 0: tile colours; 1: tiles in lexicographic sweep order")
     ap.add_argument("--tile", type=int, default=0, help="points per tile (0: automatic)")
     ap.add_argument("--cloud", default="jitter", choices=["jitter", "gmsh"], help="gmsh: quasi_uniform_square_cloud (2-D only)")
     ap.add_argument("--neumann", type=int, default=0)

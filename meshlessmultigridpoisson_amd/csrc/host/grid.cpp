@@ -346,7 +346,7 @@ double Grid::multiplier_row_value() const
 double Grid::default_mult_row = 0.0;
 int Grid::default_device_setup = -1;
 int Grid::default_point_colouring = -1;
-int Grid::default_tile_order = 0;
+int Grid::default_tile_order = -1;
 int Grid::default_sweep_min_points = 0;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,

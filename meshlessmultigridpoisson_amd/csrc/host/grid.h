@@ -65,7 +65,8 @@ public:
     int point_colouring_ = -1;   // mc_order_points, points of a tile: -1 automatic (2-D: 2, 3-D: 1), 0 greedy colours in tile order,
                                  // 1 smallest-last + iterated greedy colours, 2 lexicographic SWEEP order (no colour classes)
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring"); 2: lexicographic SWEEP order inside the tiles
-    int tile_order_ = 0;         // mc_order_points, order of the tiles: 0 by tile colour (4 / 8 phases), 1 lexicographic sweep over the tiles
+    int tile_order_ = -1;        // mc_order_points, order of the tiles: -1 automatic (2-D Neumann grids: 1, else 0), 0 by tile colour
+                                 // (4 / 8 phases), 1 lexicographic sweep over the tiles (wavefront phases)
     static int default_sweep_min_points;  // mmgh_set_option "sweep_min_points": automatic point order uses colour classes below this size
     static int default_tile_order;       // mmgh_set_option "tile_order"
     int setup_threads_ = 0;      // 0 = hardware concurrency

@@ -453,7 +453,12 @@ void Grid::mc_order_points(int tile_points)
     st.reset(new mmgh::SetupTimer("mc_order_points: storage order"));
     vector<int> torder((size_t)nt);
     std::iota(torder.begin(), torder.end(), 0);
-    if (tile_order_ == 0)
+    // automatic (-1): 2-D NEUMANN grids sweep over the tiles as well -- the multi-level Neumann cycle is marginal
+    // (DESIGN section 2c): with coloured tiles it contracts 0.90 at 256 points per tile and grows x 1.05 at 128 or 512,
+    // with the tile sweep 0.94-0.96 (polyDeg 4) / 0.59-0.66 (polyDeg 6) at every tile size tried; the price is
+    // ~3 sqrt(tiles) wavefront phases instead of 4.  Everything else keeps the coloured tiles.
+    const int tile_order = tile_order_ >= 0 ? tile_order_ : ((dim_ < 3 && neumannFlag_ && point_order == 2) ? 1 : 0);
+    if (tile_order == 0)
         std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
     else
         std::fill(tcol.begin(), tcol.end(), -1);   // tiles stay in their lexicographic (z, y, x) box order: a sweep over
@@ -482,5 +487,5 @@ void Grid::mc_order_points(int tile_points)
     apply_order(order);
     tile_ptr_ = tptr;
     tile_colour_ = tcolour;
-    if (tile_order_ != 0) tile_colour_.clear();   // no phase hints: they follow from the order
+    if (tile_order != 0) tile_colour_.clear();   // no phase hints: they follow from the order
 }

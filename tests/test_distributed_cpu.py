@@ -532,7 +532,11 @@ def test_distributed_vcycle_exact_exchange_matches_plain_oracle(neumann):
     from meshlessmultigridpoisson_amd import _host as host
     nparts = 2
     clouds = [host.square_cloud(n, seed=300 + i) for i, n in enumerate([13, 25, 41])]
-    mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
+    host.set_option("tile_order", 0)    # the exact mode numbers its phases by the tile COLOURS (2-D Neumann grids would
+    try:                                # sweep over the tiles by default: no colours, the mode is then refused)
+        mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=96)
+    finally:
+        host.set_option("tile_order", -1)
     om = H.oracle_of_multigrid(mg)
     subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
     ranks = [_Rank(host, s, r, hints=True) for r, s in enumerate(subs)]
