@@ -55,15 +55,14 @@ def test_run_tests_parameter_set_square_neumann(host, deg, nlevels, ordering):
     """All nine (grids, L) pairs of run_tests on the "square" geometry: Neumann rows at K = 37 / 52 / 70 with the
     multiplier column and the elimination fill of grid.cpp:607-661 (rows of up to ~190 entries), 8 V-cycles on the
     device follow the oracle and the final iterate agrees -- in the reference's own point order (rcm_order_points,
-    grid.cpp:713-776: a long chain of dependent tiles, exact all the same), where the cycle contracts, and in the
-    multicolour order the fast kernels are built for, where the SAME arithmetic may diverge (the marginal Neumann
-    cycle is sensitive to the relaxation order): a diverging history is followed just as closely."""
+    grid.cpp:713-776: a long chain of dependent tiles, exact all the same) and in the product's mc_order_points, which
+    on 2-D Neumann grids sweeps over the tiles and inside them (with colour classes the SAME
+    arithmetic diverges, see the "colour" case below).  The cycle contracts in both."""
     mg = host.Multigrid([host.quasi_uniform_square_cloud(s) for s in SIDES[:nlevels]], [3] * (nlevels - 1) + [deg],
                         neumann=True, ordering=host.ORDER_RCM if ordering == "rcm" else host.ORDER_MC, tile_points=0)
     om = H.oracle_of_multigrid(mg)
     hist = _follow(mg, om, 8)
-    if ordering == "rcm":
-        assert hist[-1] < hist[2], hist                  # contracts (0.58-0.88 per cycle in the oracle)
+    assert hist[-1] < hist[2], hist                      # contracts (RCM 0.58-0.88 per cycle, mc 0.45-0.97 in the oracle)
     fine = mg.grid(nlevels - 1)
     assert H.rel_err(fine.values(), om.levels[-1].x) < 1e-9
     la = fine.level_arrays()
@@ -153,3 +152,20 @@ def test_run_tests_other_geometries_neumann(host, geom, deg):
     om = H.oracle_of_multigrid(mg)
     hist = _follow(mg, om, 8)
     assert hist[-1] < hist[2], hist
+
+
+def test_colour_classes_make_the_same_cycle_diverge_and_the_gpu_follows(host):
+    """The multicolour schedule of rounds 1-2 (point_colouring 1, coloured tiles) on the 4-grid polyDeg-4 Neumann case:
+    the reference's arithmetic, another relaxation order -- the cycle grows x 1.8 per cycle in the CPU oracle, and the
+    device follows the diverging history to the same tolerance.  (Why the default order is a sweep: DESIGN 2c.)"""
+    host.set_option("point_colouring", 1)
+    host.set_option("tile_order", 0)
+    try:
+        mg = host.Multigrid([host.quasi_uniform_square_cloud(s) for s in SIDES], [3, 3, 3, 4], neumann=True,
+                            ordering=host.ORDER_MC, tile_points=0)
+    finally:
+        host.set_option("point_colouring", -1)
+        host.set_option("tile_order", -1)
+    om = H.oracle_of_multigrid(mg)
+    hist = _follow(mg, om, 8)
+    assert hist[-1] > 3.0 * hist[2], hist
