@@ -1103,7 +1103,10 @@ LevelLayout level_layout(long long n_points, double avg_row_len)
         if (n_points <= 400000) return {true, 256, 16, 4};    // 11 rows per level: rounds of 4 x 4 rows, 4 entries per lane
         if (n_points <= 1500000) return {true, 512, 16, 6};   // bandwidth starts to matter: fuller rounds (108^3: 217-224 us; 8 lanes x 7 entries: 293)
         if (n_points <= 2600000) return {true, 1024, 16, 12}; // 128^3: 312 us (T 384 / 4 wavefronts: 357; packed 473)
-        if (n_points <= 4000000) return {true, 1024, 16, 6};  // 150^3: 451 us = 56 % (T 512: 502; packed 553)
+        // 150^3: 423 us = 60 % with the extra entry plane (446 without; T 512: 502; packed 531); 171^3 = 5.0e6 points (the
+        // per-GPU level of BASELINE configs[3] on 8 GPUs): 575-582 us = 65-66 % (packed 644-673 = 56-59 %; T 1536: 629,
+        // 2048: 675; 12 wavefronts: 648); 190^3: 781 us = 67 % (packed 828 = 63 %); 216^3: 1128 us = 68 % -- packed 80 %.
+        if (n_points <= 7500000) return {true, 1024, 16, 6};
         return {false, 0, 0, 1};
     }
     if (avg_row_len <= 30.0) {  // 2-D K = 25 (the coarse levels of the reference's hierarchies)
