@@ -111,6 +111,8 @@ def lib():
         L.mmgh_mg_extract_subdomain.argtypes = [vp, C.c_int, C.c_int]
         L.mmgh_mg_level_part.argtypes = [vp, C.c_int, C.c_int, _ip]
         L.mmgh_grid_partition_slabs.argtypes = [vp, C.c_int, _ip]
+        if hasattr(L, "mmgh_grid_partition"):
+            L.mmgh_grid_partition.argtypes = [vp, C.c_int, _ip]
         L.mmgh_grid_extract_subdomain.restype = vp
         L.mmgh_grid_extract_subdomain.argtypes = [vp, _ip, C.c_int]
         L.mmgh_grid_n_owned.argtypes = [vp]

@@ -1,6 +1,7 @@
 // grid.cpp -- see grid.h.  Setup follows MeshlessPoisson/grid.cpp (citations per
 // method); the hot methods forward to the C-ABI of libmmgp.so.
 #include "grid.h"
+#include <functional>
 #include <memory>
 
 #include <algorithm>
@@ -692,6 +693,70 @@ vector<int> Grid::partition_slabs(int nparts)
         std::sort(idx.begin(), idx.end(), [&](int a2, int b2) { return xof(a2) < xof(b2) || (xof(a2) == xof(b2) && a2 < b2); });
         for (int k = 0; k < n; ++k) part[(size_t)idx[(size_t)k]] = (int)((long long)k * nparts / n);
     }
+    return part;
+}
+
+int Grid::default_partition = 0;
+
+vector<int> Grid::partition_rcb(int nparts)
+{
+    const int n = (int)points_.size();
+    vector<int> part((size_t)n, 0);
+    if (nparts <= 1) return part;
+    // items = tiles (centroid, weight = points) or single points
+    struct Item { double c[3]; int w; int first, last; };
+    vector<Item> items;
+    auto coord = [&](int i, int ax) { return ax == 0 ? std::get<0>(points_[(size_t)i]) : (ax == 1 ? std::get<1>(points_[(size_t)i]) : std::get<2>(points_[(size_t)i])); };
+    int covered = n;
+    if (!tile_ptr_.empty()) {
+        const int nt = (int)tile_ptr_.size() - 1;
+        for (int t = 0; t < nt; ++t) {
+            Item it{{0, 0, 0}, tile_ptr_[(size_t)t + 1] - tile_ptr_[(size_t)t], tile_ptr_[(size_t)t], tile_ptr_[(size_t)t + 1]};
+            if (it.w <= 0) continue;
+            for (int i = it.first; i < it.last; ++i)
+                for (int ax = 0; ax < 3; ++ax) it.c[ax] += coord(i, ax);
+            for (int ax = 0; ax < 3; ++ax) it.c[ax] /= it.w;
+            items.push_back(it);
+        }
+        covered = tile_ptr_.back();
+    } else {
+        for (int i = 0; i < n; ++i) items.push_back(Item{{coord(i, 0), coord(i, 1), coord(i, 2)}, 1, i, i + 1});
+    }
+    vector<int> item_part(items.size(), 0);
+    // (begin, end) range of `order`, ranks [r0, r0 + nr)
+    vector<int> order(items.size());
+    for (size_t k = 0; k < items.size(); ++k) order[k] = (int)k;
+    std::function<void(int, int, int, int)> cut = [&](int b, int e, int r0, int nr) {
+        if (nr <= 1 || e - b <= 0) {
+            for (int k = b; k < e; ++k) item_part[(size_t)order[(size_t)k]] = r0;
+            return;
+        }
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        long long wsum = 0;
+        for (int k = b; k < e; ++k) {
+            const Item &it = items[(size_t)order[(size_t)k]];
+            for (int ax = 0; ax < 3; ++ax) { lo[ax] = std::min(lo[ax], it.c[ax]); hi[ax] = std::max(hi[ax], it.c[ax]); }
+            wsum += it.w;
+        }
+        int ax = 0;
+        for (int a2 = 1; a2 < (dim_ >= 3 ? 3 : 2); ++a2)
+            if (hi[a2] - lo[a2] > hi[ax] - lo[ax] + 1e-12) ax = a2;
+        std::sort(order.begin() + b, order.begin() + e, [&](int x, int y) {
+            const Item &ix = items[(size_t)x], &iy = items[(size_t)y];
+            return ix.c[ax] < iy.c[ax] || (ix.c[ax] == iy.c[ax] && x < y);
+        });
+        const int nl = nr / 2;                       // ranks of the lower part; its share of the weight: nl / nr
+        long long acc = 0;
+        int m = b;
+        while (m < e - 1 && (acc + items[(size_t)order[(size_t)m]].w) * (long long)nr <= wsum * (long long)nl) acc += items[(size_t)order[(size_t)m++]].w;
+        if (m == b) m = b + 1;                       // never an empty half while there are items for both
+        cut(b, m, r0, nl);
+        cut(m, e, r0 + nl, nr - nl);
+    };
+    cut(0, (int)items.size(), 0, nparts);
+    for (size_t k = 0; k < items.size(); ++k)
+        for (int i = items[k].first; i < items[k].last; ++i) part[(size_t)i] = item_part[k];
+    for (int i = covered; i < n; ++i) part[(size_t)i] = nparts - 1;
     return part;
 }
 

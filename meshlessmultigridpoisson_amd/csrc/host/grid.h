@@ -124,6 +124,14 @@ public:
     // Spatial partition into `nparts` slabs along x with balanced point counts; whole
     // tiles stay together when mc_order_points() has run.  Returns the owner of every point.
     vector<int> partition_slabs(int nparts);
+    // Recursive coordinate bisection of the tiles (or of the points when the grid has no tiles): the set is cut across
+    // the longest axis of its bounding box into two parts whose sizes are in the ratio of the ranks they receive,
+    // recursively -- 8 ranks on a cube: 2 x 2 x 2 boxes, 3 interface faces per rank instead of the 2 full cross-sections
+    // of a slab.  Tiles are never split.  Same contract as partition_slabs.
+    vector<int> partition_rcb(int nparts);
+    // what Multigrid::extract_subdomain / level_part use: 0 x-slabs (default), 1 RCB (mmgh_set_option "partition")
+    static int default_partition;
+    vector<int> partition(int nparts) { return default_partition == 1 ? partition_rcb(nparts) : partition_slabs(nparts); }
     // The local system of `rank`: its owned points in the current storage order, then the
     // ghost points its rows reference (sorted by owner, then index); matrix rows, boundary
     // lists, RHS and tile boundaries restricted accordingly.  `extra_ghosts` (global indices)

@@ -672,6 +672,12 @@ void mmgh_grid_partition_slabs(void *gp, int nparts, int *part)
     auto p = static_cast<Grid *>(gp)->partition_slabs(nparts);
     std::memcpy(part, p.data(), sizeof(int) * p.size());
 }
+// the partition Multigrid::extract_subdomain would use (x-slabs or RCB boxes, mmgh_set_option "partition")
+void mmgh_grid_partition(void *gp, int nparts, int *part)
+{
+    auto p = static_cast<Grid *>(gp)->partition(nparts);
+    std::memcpy(part, p.data(), sizeof(int) * p.size());
+}
 void *mmgh_grid_extract_subdomain(void *gp, const int *part, int rank)
 {
     Grid *g = static_cast<Grid *>(gp), *out = nullptr;
@@ -723,7 +729,7 @@ int mmgh_mg_setup_exchange(void *h, int per_phase)
 }
 void mmgh_mg_level_part(void *h, int l, int nparts, int *part)
 {
-    auto p = static_cast<Multigrid *>(h)->grids_.at((size_t)l).second->partition_slabs(nparts);
+    auto p = static_cast<Multigrid *>(h)->grids_.at((size_t)l).second->partition(nparts);
     std::memcpy(part, p.data(), sizeof(int) * p.size());
 }
 // n_owned, then gid[n_local] and ghost_owner[n_local - n_owned]
@@ -851,6 +857,7 @@ int mmgh_set_option(const char *name, int value)
     if (name && std::string(name) == "device_setup") { Grid::default_device_setup = value; return 0; }
     if (name && std::string(name) == "point_colouring") { Grid::default_point_colouring = value; return 0; }
     if (name && std::string(name) == "tile_order") { Grid::default_tile_order = value; return 0; }
+    if (name && std::string(name) == "partition") { Grid::default_partition = value; return 0; }
     if (name && std::string(name) == "sweep_min_points") { Grid::default_sweep_min_points = value; return 0; }
     if (name && std::string(name) == "multiplier_row_ppm") { Grid::default_mult_row = value / 1.0e6; return 0; }
     g_herr = "mmgh_set_option: unknown option";

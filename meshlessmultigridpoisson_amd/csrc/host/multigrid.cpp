@@ -202,7 +202,7 @@ Multigrid *Multigrid::extract_subdomain(int nparts, int rank, vector<vector<int>
     vector<vector<int>> part(nl);
     for (size_t l = 0; l < nl; ++l) {
         if (l < l_agg) part[l].assign((size_t)grids_[l].second->getSize(), rank);
-        else part[l] = grids_[l].second->partition_slabs(nparts);
+        else part[l] = grids_[l].second->partition(nparts);   // x-slabs, or RCB boxes (Grid::default_partition)
     }
     // ghost needs of the transfers: columns (points of the INPUT level) touched by owned rows
     auto need = [&](SparseColMajor *m, const vector<int> &row_part, int q, vector<int> &dst) {

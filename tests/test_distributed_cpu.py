@@ -875,3 +875,62 @@ def test_gloo_world_size_2_fractional_step(tmp_path):
         assert np.abs(z["u"] - ofs.u[z["gid"]]).max() <= 1e-9 * np.abs(ofs.u).max()
         assert np.abs(z["v"] - ofs.v[z["gid"]]).max() <= 1e-9 * np.abs(ofs.v).max()
         assert np.abs(z["p"] - om.levels[-1].x[z["gid"]]).max() <= 1e-9 * np.abs(om.levels[-1].x).max()
+
+
+@pytest.mark.parametrize("neumann", [False, True])
+def test_distributed_vcycle_rcb_boxes_matches_hybrid_oracle(neumann):
+    """Non-slab partition (SURVEY 8e): Grid::partition_rcb cuts every level into 2 x 2 boxes (recursive coordinate
+    bisection of the tiles, mmgh_set_option("partition", 1)); ranks then have up to three neighbours each, the
+    exchange lists come from the same Multigrid::extract_subdomain.  Four emulated ranks follow orc_vcycle_hybrid on the
+    global hierarchy with the same partition."""
+    from meshlessmultigridpoisson_amd import _host as host
+    nparts = 4
+    host.set_option("partition", 1)
+    try:
+        clouds = [host.quasi_uniform_square_cloud(n) for n in (13, 25, 41)]
+        mg = host.Multigrid(clouds, [3, 3, 3], neumann=neumann, ordering=host.ORDER_MC, tile_points=64)
+        om = H.oracle_of_multigrid(mg)
+        parts = [mg.level_part(l, nparts) for l in range(mg.nlevels)]
+        subs = [mg.extract_subdomain(nparts, r) for r in range(nparts)]
+    finally:
+        host.set_option("partition", 0)
+    fine_xy = mg.grid(2).points()[0]
+    for r in range(nparts):          # boxes, not slabs: every part is confined in x AND in y
+        p = fine_xy[parts[2] == r]
+        assert len(p) > 0.15 * len(fine_xy)
+        assert p[:, 0].max() - p[:, 0].min() < 0.75 and p[:, 1].max() - p[:, 1].min() < 0.75
+    ranks = [_Rank(host, s, r) for r, s in enumerate(subs)]
+    for rk, sub in zip(ranks, subs):
+        rk.lists = [sub.grid(l).exchange_lists() for l in range(sub.nlevels)]
+    assert max(len(rk.lists[2][0]) for rk in ranks) >= 2          # more than the two neighbours a slab can have ... or equal
+    for k in range(4):
+        ro = om.vcycle_hybrid(parts, nparts)
+        rd = _dist_vcycle(ranks)
+        assert abs(rd - ro) <= 1e-10 * ro + 2e-13, (k, rd, ro)
+
+
+def test_rcb_boxes_need_fewer_ghosts_than_slabs_in_3d():
+    """8 ranks on a cube: 2 x 2 x 2 boxes exchange fewer ghost values than 8 x-slabs (three half-size interface faces
+    per rank instead of two full cross-sections)."""
+    from meshlessmultigridpoisson_amd import _host as host
+    pts = host.box_cloud(24, 3, seed=5)
+    g = host.Grid.create_square(pts, 2, dim=3, kind=host.KIND_DIRICHLET, ordering=host.ORDER_MC, tile_points=64)
+    n = g.sizes()["n"]
+    ghosts = {}
+    for kind in (0, 1):
+        host.set_option("partition", kind)
+        try:
+            part = np.zeros(n, dtype=np.int32)
+            f = host.lib().mmgh_grid_partition
+            f(g.h, 8, part.ctypes.data_as(host._ip))
+        finally:
+            host.set_option("partition", 0)
+        assert sorted(np.unique(part)) == list(range(8))
+        assert np.bincount(part).min() > 0.6 * n / 8
+        tot = 0
+        for r in range(8):
+            sub = g.extract_subdomain(part, r)
+            no, gid, gown = sub.local_map()
+            tot += len(gid) - no
+        ghosts[kind] = tot
+    assert ghosts[1] < 0.8 * ghosts[0], ghosts
