@@ -264,3 +264,27 @@ def rho_evaluation_noise(lv):
 def rel_err(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def ragged_level(n, seed, max_len=40, dirichlet_frac=0.0):
+    """A level outside anything a stencil generator produces: random diagonally dominant CSR with RAGGED rows (1 ..
+    max_len stored entries, the 1-entry rows holding the diagonal only), optionally a share of Dirichlet points."""
+    rng = np.random.default_rng(seed)
+    rowptr, col, val = [0], [], []
+    flags = (rng.random(n) < dirichlet_frac).astype(np.int32)
+    for i in range(n):
+        k = int(rng.integers(1, max(2, min(max_len, n)) + 1))
+        others = (rng.choice(np.delete(np.arange(n), i), size=min(k - 1, n - 1), replace=False) if n > 1
+                  else np.zeros(0, dtype=np.int64))
+        c = np.sort(np.append(others, i)).astype(np.int64)
+        v = -rng.random(len(c))
+        v[c == i] = 1.0 + len(c)
+        col += c.tolist()
+        val += v.tolist()
+        rowptr.append(len(col))
+    bpts = np.flatnonzero(flags).astype(np.int32)
+    nb = 1 if len(bpts) else 0
+    return dict(n=n, a_size=n, rowptr=np.array(rowptr, dtype=np.int32), col=np.array(col, dtype=np.int32), val=np.array(val),
+                bcflags=flags, neumann=0, omega=1.3, iters=2, btype=np.full(nb, 1, dtype=np.int32),
+                bptr=np.array([0, len(bpts)][: nb + 1], dtype=np.int32), bpts=bpts, bvals=rng.standard_normal(len(bpts)),
+                x0=rng.standard_normal(n), b0=rng.standard_normal(n))

@@ -717,3 +717,29 @@ def test_full_size_properties_1e7_points():
         seen = np.where((c[off] < i) & interior[c[off]], xs[c[off]], x1[c[off]])
         want = (1 - 1.4) * x1[i] + 1.4 / d * (b1[i] - (v[off] * seen).sum())
         assert abs(xs[i] - want) <= 1e-11 * max(1.0, abs(want)), i
+
+
+@pytest.mark.parametrize("n,max_len,dfrac", [(1, 1, 0.0), (2, 2, 0.0), (65, 3, 0.0), (300, 40, 0.2), (257, 200, 0.0), (120, 20, 1.0)])
+@pytest.mark.parametrize("waves", [0, 1, 4])
+def test_edge_case_levels_on_device(n, max_len, dfrac, waves):
+    """SURVEY 8c edge cases through the C-ABI: a level of one point, of two, ragged rows of 1 ... 200 entries
+    (diagonal-only rows included), 20 % Dirichlet points, a level of Dirichlet points only (nothing is relaxed, the
+    masked residual is zero, the ratio is 0 / ||b|| = 0).  Automatic, packed and dense layouts; sweeps, residual vector
+    and residual ratio equal the oracle's; zero sweeps change nothing."""
+    _need_gpu()
+    la = H.ragged_level(n, seed=n + max_len, max_len=max_len, dirichlet_frac=dfrac)
+    o = H.oracle_level(la)
+    d = H.device_level(la, tile_size=64, waves_per_tile=waves)
+    o.boundary_op(0)
+    d.boundary_op(0)
+    assert np.array_equal(d.get_x(), o.x)
+    d.sweeps(0)
+    assert np.array_equal(d.get_x(), o.x)
+    o.sor_sweeps(3)
+    d.sweeps(3)
+    assert H.rel_err(d.get_x(), o.x) < 1e-12
+    ro, rd = o.residual(), d.residual()
+    assert np.abs(rd - ro).max() <= 1e-11 * max(1.0, np.abs(ro).max())
+    assert abs(d.residual_ratio() - o.residual_ratio()) <= 1e-10 * o.residual_ratio() + 1e-15
+    info = d.info()
+    assert info["sor_rows"] == int((la["bcflags"] == 0).sum())
