@@ -75,9 +75,11 @@ def test_auto_tile_points_is_device_free_arithmetic():
     assert _capi.auto_tile_points(250000, 2, 25, 0, 256, 163840) == 256
     assert _capi.auto_tile_points(1000000, 2, 37, 0, 256, 163840) == 512
     assert _capi.auto_tile_points(4000000, 2, 37, 4, 256, 163840) >= 256     # packed stream beyond the dense regime
-    # mid-size levels are bound by 8 phases x one tile's duration: small tiles (measured 171^3, 190^3)
-    assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 384
-    assert _capi.auto_tile_points(190 ** 3, 3, 50, 0, 256, 163840) == 384
+    # 4e6 ... 7.5e6 points (round 3): dense layout with the extra entry plane, 1024-point tiles (measured 171^3: 65 %
+    # against 57 % for the packed stream with 384-point tiles; 190^3: 67 against 63 %); beyond it the packed stream
+    assert _capi.auto_tile_points(171 ** 3, 3, 50, 2, 256, 163840) == 1024
+    assert _capi.auto_tile_points(190 ** 3, 3, 50, 0, 256, 163840) == 1024
+    assert _capi.auto_tile_points(200 ** 3, 3, 50, 0, 256, 163840) in (384, 1280)
     assert _capi.auto_tile_points(10000, 2, 37, 4, 256, 163840) == 256
 
 
