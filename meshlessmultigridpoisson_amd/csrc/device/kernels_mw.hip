@@ -311,6 +311,15 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
 // register sets per wavefront: a group is 4 ... 7 load instructions, 14 ... 26 registers
 template <int P>
 constexpr int kDepthMw = P <= 4 ? 4 : 3;
+// ONE wavefront per tile (sweep-ordered levels): a round is one group and takes ~0.3 us, so 3-4 rounds of prefetch
+// cover ~1 us -- less than an HBM round trip under load (the 1e6-point level ran 68-100 rounds per tile at ~0.6 us
+// each, i.e. at memory latency / depth).  With the whole SIMD's register file to itself the wavefront keeps 8 (6)
+// rounds in flight: MMG_MW1_DEPTH overrides at compile time for A/B.
+#ifndef MMG_MW1_DEPTH
+#define MMG_MW1_DEPTH 0
+#endif
+template <int P, int NW>
+constexpr int kDepthFor = NW == 1 ? (MMG_MW1_DEPTH > 0 ? MMG_MW1_DEPTH : (P <= 4 ? 8 : 6)) : kDepthMw<P>;
 
 // one launch per phase: one workgroup of NW wavefronts per tile
 template <int L, int MODE, int P, int NW, bool LONG = false, bool X = false>
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel_mw(TileArgs a)
     const int tile = a.tile_list ? a.tile_list[idx] : idx;
     double lam = 0.0;
     if (a.lambda) lam = *a.lambda;
-    process_tile_mw<L, MODE, P, false, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
+    process_tile_mw<L, MODE, P, false, NW, kDepthFor<P, NW>, LONG, X>(a, tile, smem, lam);
 }
 
 // Workgroup-wide broadcast of a value that wavefront 0 holds (the same in all its lanes).
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_resident_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<2>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthFor<P, NW>, LONG, X>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have; LDS free for the next sweep
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) void sweep_persistent_mw(TileArgs a)
         unsigned ok = 0;
         if (wave0) ok = wait_for_tiles<8>(a, tile, d0, d1, l0, l1, want_now, want_prev) ? 1u : 0u;
         ok = wg_bcast(ok, wave0, &ctl);
-        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthMw<P>, LONG, X>(a, tile, smem, lam);
+        if (ok) process_tile_mw<L, MODE_SOR, P, true, NW, kDepthFor<P, NW>, LONG, X>(a, tile, smem, lam);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's x stores have reached L2 ...
         __syncthreads();                                   // ... everybody's have
         if (wave0) __hip_atomic_store(a.done + tile, want_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
