@@ -182,6 +182,13 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         for (int q = 0; q < P; ++q) xv[q] = xs[dense_slot<P>(g, q)];
         double xx = 0.0;
         if (X) xx = xs[g.info.y >> 17];     // the extra entry's column (empty: the zero slot)
+        // The row's own x and rhs are requested WITH the gathers, not after the reduction: they do not depend on the
+        // row sum, and behind it they were one more LDS round trip on the critical path of every round (the
+        // chain-bound levels pay rounds x this latency).  Rows of a round are distinct and mutually uncoupled and the
+        // previous round's writes are complete (barrier), so the value read here is the one the update needs.
+        const uint32_t self_pre = g.info.y & 0xffffu;
+        const double x_self = xs[self_pre < n_slots ? self_pre : n_slots - 1];
+        const double b_self = bs[self_pre < n_own ? self_pre : 0];   // (n_own > 0 whenever the tile has rows)
         __builtin_amdgcn_sched_barrier(0);  // every gather in flight before the first FMA
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -213,14 +220,14 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
             const uint32_t self = g.info.y & 0xffffu, flags = g.info.y >> 16;  // (dense_xtra: bits 1..15 hold the extra slot)
             const double invd = __longlong_as_double(((unsigned long long)g.info.w << 32) | g.info.z);
             if (MODE == MODE_SOR) {
-                double xi = bs[self] - acc;
+                double xi = b_self - acc;
                 if (flags & 1) xi -= lam;
                 xi *= a.omega * invd;
-                xi = fma(om1, xs[self], xi);
+                xi = fma(om1, x_self, xi);
                 xs[self] = xi;
             } else {  // MODE_RESID
-                const double bi = (self < n_own) ? bs[self] : a.b[gid];
-                double rr = bi - fma(g.diag, xs[self], acc);
+                const double bi = (self < n_own) ? b_self : a.b[gid];
+                double rr = bi - fma(g.diag, x_self, acc);
                 if (flags & 1) rr -= lam;
                 if (a.resid_lds && self < n_own) bs[self] = rr;
                 else a.out[gid] = rr;

@@ -19,8 +19,8 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v)
 {
     const unsigned long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, true);
     return v + __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
