@@ -564,6 +564,23 @@ void *mmgh_fs_create_square(int n, const double *xyz, int polydeg, double dt, do
     if (guard([&]() { g = gen_fs_grid(n, xyz, 2, polydeg, dt, mu, rho, ordering, tile_points, coarse); })) { delete g; return nullptr; }
     return g;
 }
+// ADVICE r2 (operator cache): D_x with the grid's polyDeg (fills the cache of one device batch with all operators),
+// then polyDeg changed and D_y rebuilt -- the reference rebuilds every operator from the current state
+// (fractionalStepGrid.cpp:60-100), so D_y must come out with the NEW stencil size, not from the stale batch.
+// Returns entries per row of D_x and of the rebuilt D_y through out2.
+int mmgh_fs_rebuild_after_polydeg_change(void *gp, int new_polydeg, int *out2)
+{
+    return guard([&]() {
+        FractionalStepGrid *g = static_cast<FractionalStepGrid *>(gp);
+        g->build_derivX_mat();
+        out2[0] = g->derivXMat_->nonZeros() / std::max(1, g->derivXMat_->rows());
+        const GridProperties np = make_props(new_polydeg, g->dim_, g->properties_.omega, g->properties_.iters);
+        g->properties_.polyDeg = np.polyDeg;
+        g->properties_.stencilSize = np.stencilSize;
+        g->build_derivY_mat();
+        out2[1] = g->derivYMat_->nonZeros() / std::max(1, g->derivYMat_->rows());
+    });
+}
 void *mmgh_fs_create_box(int n, const double *xyz, int dim, int polydeg, double dt, double mu, double rho, int ordering,
                          int tile_points, int coarse)
 {

@@ -355,3 +355,21 @@ def test_knn_flagged_query_rule_on_coincident_boundary_points(host):
             assert list(got[i][2:]) == ref[1:k - 1]
         else:
             assert list(got[i]) == ref, i
+
+
+def test_fracstep_operator_cache_follows_polydeg_changes(host):
+    """the operators of one device batch (D_x, D_y, lap from ONE factorisation per point) are cached until
+    fetched; the cache is keyed on everything the stencils depend on.  D_x built at polyDeg 3 (K = 25), polyDeg then
+    set to 4: the next build_derivY_mat must deliver K = 37 rows -- the reference rebuilds each operator from the
+    current state (fractionalStepGrid.cpp:60-100)."""
+    import ctypes
+    host.set_option("device_setup", 1)
+    try:
+        g = host.FracStepGrid.create(host.quasi_uniform_square_cloud(41), polydeg=3, ordering=host.ORDER_MC, tile_points=128)
+        out = (ctypes.c_int * 2)()
+        f = host.lib().mmgh_fs_rebuild_after_polydeg_change
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        assert f(g.h, 4, out) == 0, host._err()
+    finally:
+        host.set_option("device_setup", -1)
+    assert (out[0], out[1]) == (host.stencil_size(3), host.stencil_size(4))
