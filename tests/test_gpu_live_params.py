@@ -169,3 +169,32 @@ def test_colour_classes_make_the_same_cycle_diverge_and_the_gpu_follows(host):
     om = H.oracle_of_multigrid(mg)
     hist = _follow(mg, om, 8)
     assert hist[-1] > 3.0 * hist[2], hist
+
+
+def test_single_grid_loop_of_testGmshSingleGrid(host):
+    """testGmshSingleGrid as the reference has it live (testing_functions.cpp:422-442): "square_with_circle", Dirichlet,
+    polyDeg 6 (K = 70), omega 1.4, `boundaryOp("fine")`, then `residual ratio; sor` in a loop, on a Gmsh-like cloud of the
+    reference's size class (square_hole_10197.msh -> 8813 points here).  Grid::boundaryOp / residual / sor run on the
+    device; the printed ratios follow the oracle call by call, and the iterate approaches sin sin."""
+    cloud = host.quasi_uniform_square_with_circle_cloud(97)
+    mg = host.Multigrid.square_with_circle([cloud], [6], k=1, ordering=host.ORDER_RCM)
+    g = mg.grid(0)
+    la = g.level_arrays()
+    assert int(np.diff(la["rowptr"]).max()) == host.stencil_size(6)
+    o = H.oracle_level(la)
+    g.boundary_op(False)
+    o.boundary_op(0)
+    hist = []
+    for k in range(40):
+        ro, rd = o.residual_ratio(), g.residual_ratio()
+        assert abs(rd - ro) <= 1e-10 * ro + max(FLOOR, H.rho_evaluation_noise(o)), (k, rd, ro)
+        hist.append(rd)
+        g.sor()
+        o.sor()
+    assert H.rel_err(g.values(), o.x) < 1e-10
+    assert hist[-1] < hist[1]                       # the single-grid loop converges (slowly: it is plain SOR)
+    xyz, _fl = g.points()
+    n = g.sizes()["n"]
+    exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
+    e0 = np.abs(exact).sum() / n                    # the error of the zero start
+    assert np.abs(g.values()[:n] - exact).sum() / n < e0
