@@ -198,3 +198,32 @@ def test_single_grid_loop_of_testGmshSingleGrid(host):
     exact = np.sin(np.pi * xyz[:, 0]) * np.sin(np.pi * xyz[:, 1])
     e0 = np.abs(exact).sum() / n                    # the error of the zero start
     assert np.abs(g.values()[:n] - exact).sum() / n < e0
+
+
+def test_run_frac_step_test_first_time_steps(host):
+    """What the reference's main() runs (main.cpp:4-8 -> run_frac_step_test, FractionalStepSim.cpp:201-203 ->
+    run_fracstep_param :114-156): Kovasznay flow, 4 grids, fine polyDeg 6, dt = 2e-4, mu = 0.025, rho = 1, pressure loop
+    `while (mg.residual() >= 1e-10) { vCycle; bound_eval_neumann }` -- here on Gmsh-like clouds of 185 ... 10 874 points in
+    the reference's RCM order, two time steps device-resident (mmg_fracstep_step) against the same loop over oracle
+    objects: the pressure loop converges (not capped), in the same number of V-cycles, with the same fields."""
+    clouds = [host.quasi_uniform_square_cloud(s) for s in SIDES]
+    mg = host.FracStepMultigrid(clouds, [3, 3, 3, 6], dim=2, dt=2e-4, mu=0.025, rho=1.0, ordering=host.ORDER_RCM, tile_points=0)
+    g = mg.fs_grid()
+    n = g.sizes()["n"]
+    g.prescribe_soln()
+    g.set_uv_bound()
+    om = H.oracle_of_multigrid(mg)
+    assert om.frac_step and len(om.levels) == 4
+    ofs = H.oracle_of_fracstep(g)
+    ofs.u[:], ofs.v[:] = g.vec(0), g.vec(1)
+    _bt, _bp, bpts, _bv = g.boundaries()
+    _xyz, flags = g.points()
+    arrays = dict(bpts=bpts, bvals=[ofs.u[bpts].copy(), ofs.v[bpts].copy()], coupling=g.coupling(), bcflags=flags)
+    for step in range(2):
+        r_dev, nc_dev = mg.step(max_cycles=400)
+        r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 400)
+        assert nc_dev < 400 and abs(nc_dev - nc_orc) <= 1, (step, nc_dev, nc_orc)      # converged, not capped
+        assert abs(r_dev - r_orc) <= 1e-6 * abs(r_orc), (step, r_dev, r_orc)
+        for got, want in zip((g.vec(0), g.vec(1)), (ofs.u, ofs.v)):
+            assert H.rel_err(got, want) < 1e-6, step
+        assert H.rel_err(g.values()[:n], om.levels[-1].x[:n]) < 1e-5, step
