@@ -129,8 +129,9 @@ int rccl_load()
     RSYM(AllReduce, "ncclAllReduce")
     RSYM(AllGather, "ncclAllGather")
     RSYM(GetErrorString, "ncclGetErrorString")
-    RSYM(CommCount, "ncclCommCount")
-    RSYM(CommUserRank, "ncclCommUserRank")
+    // read-back of the communicator (evidence only): optional, mmg_comm_info falls back to what mmg_comm_init was given
+    *(void **)(&g_rccl.CommCount) = dlsym(g_rccl.so, "ncclCommCount");
+    *(void **)(&g_rccl.CommUserRank) = dlsym(g_rccl.so, "ncclCommUserRank");
 #undef RSYM
     return MMG_OK;
 }
@@ -1555,9 +1556,11 @@ int mmg_comm_init(int rank, int nranks, const char *id128)
 int mmg_comm_info(int *nranks, int *rank)
 {
     if (!g_rccl.comm) return fail(MMG_ERR_COMM, "mmg_comm_init has not been called");
-    int n = 0, r = -1;
-    NCCLC(g_rccl.CommCount(g_rccl.comm, &n));      // read back from RCCL, not the values mmg_comm_init was given
-    NCCLC(g_rccl.CommUserRank(g_rccl.comm, &r));
+    int n = g_rccl.nranks, r = g_rccl.rank;
+    if (g_rccl.CommCount && g_rccl.CommUserRank) {  // read back from RCCL, not the values mmg_comm_init was given
+        NCCLC(g_rccl.CommCount(g_rccl.comm, &n));
+        NCCLC(g_rccl.CommUserRank(g_rccl.comm, &r));
+    }
     if (nranks) *nranks = n;
     if (rank) *rank = r;
     return MMG_OK;

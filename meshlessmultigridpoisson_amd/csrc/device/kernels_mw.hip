@@ -316,8 +316,11 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
 }
 
 // register sets per wavefront: a group is 4 ... 7 load instructions, 14 ... 26 registers
+#ifndef MMG_MW_DEPTH
+#define MMG_MW_DEPTH 0
+#endif
 template <int P>
-constexpr int kDepthMw = P <= 4 ? 4 : 3;
+constexpr int kDepthMw = MMG_MW_DEPTH > 0 ? MMG_MW_DEPTH : (P <= 4 ? 4 : 3);
 // ONE wavefront per tile (sweep-ordered levels): a round is one group and takes ~0.3 us, so 3-4 rounds of prefetch
 // cover ~1 us -- less than an HBM round trip under load (the 1e6-point level ran 68-100 rounds per tile at ~0.6 us
 // each, i.e. at memory latency / depth).  With the whole SIMD's register file to itself the wavefront keeps 8 (6)
