@@ -43,7 +43,7 @@ def main():
             lv.sweeps(2)
             ms = lv.time_sweeps(1, 3)
             buf = (C.c_ulonglong * (4 * nt))()
-            _capi.check(L.mmg_debug_timing_tiles(buf, nt, int(info["waves_per_tile"] > 1)))
+            _capi.check(L.mmg_debug_timing_tiles(buf, nt, int(info["waves_per_tile"] != 1)))
             st = np.frombuffer(buf, dtype=np.uint64).reshape(nt, 4).astype(np.float64) * 0.01  # us (100 MHz)
             ok = st[:, 3] > 0
             st = st[ok]
