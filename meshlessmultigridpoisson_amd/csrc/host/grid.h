@@ -64,6 +64,16 @@ public:
     int geom_version_ = 0;       // bumped by apply_order: caches keyed on the point order compare it
     int point_colouring_ = -1;   // mc_order_points, points of a tile: -1 automatic (2-D: 2, 3-D: 1), 0 greedy colours in tile order,
                                  // 1 smallest-last + iterated greedy colours, 2 lexicographic SWEEP order (no colour classes)
+    double tile_aspect_ = 4.0;   // point order 3: width / height of a tile (flat tiles: the depth of a tile is 4 x its rows)
+    // mc_order_points' point order with the automatic choice resolved: 0 / 1 colour classes, 2 lexicographic sweep,
+    // 3 rows ascending + 4 colours along a row
+    int resolve_point_order() const
+    {
+        int po = point_colouring_ >= 0 ? point_colouring_ : (dim_ >= 3 ? 1 : 2);
+        if (point_colouring_ < 0 && po == 2 && (int)points_.size() < default_sweep_min_points) po = 1;  // experiment
+        if (po == 3 && dim_ >= 3) po = 1;
+        return po;
+    }
     static int default_point_colouring;  // value new grids start with (mmgh_set_option "point_colouring"); 2: lexicographic SWEEP order inside the tiles
     int tile_order_ = -1;        // mc_order_points, order of the tiles: -1 automatic (2-D Neumann grids: 1, else 0), 0 by tile colour
                                  // (4 / 8 phases), 1 lexicographic sweep over the tiles (wavefront phases)

@@ -219,6 +219,14 @@ void Grid::mc_order_points(int tile_points)
         for (int a2 = 0; a2 < dim_; ++a2) vol *= ext[a2];
         for (int a2 = 0; a2 < dim_; ++a2)
             m[a2] = std::max(1, (int)std::floor(std::pow(n_leaf / vol, 1.0 / dim_) * ext[a2] + 0.5));
+        // point order 3 (rows ascending, 4 colours along a row): the dependency depth of a tile is 4 x its rows, so the
+        // tiles are made FLAT -- tile_aspect_ times as wide (x) as tall (y); at least ~8 rows tall (the parity colouring
+        // of the tiles needs more than one stencil reach in every direction)
+        if (dim_ == 2 && resolve_point_order() == 3 && tile_aspect_ > 1.0) {
+            const double m0 = std::sqrt(n_leaf * (ext[0] / ext[1]) / tile_aspect_);
+            m[0] = std::max(1, (int)std::floor(m0 + 0.5));
+            m[1] = std::max(1, (int)std::floor(n_leaf / m[0] + 0.5));
+        }
         while ((double)m[0] * m[1] * m[2] * tile_points < (double)n_t) {  // keep tiles <= tile_points
             int best = 0;
             for (int a2 = 1; a2 < dim_; ++a2)
@@ -334,8 +342,7 @@ void Grid::mc_order_points(int tile_points)
     // automatic (-1): 2-D clouds get the sweep order (the reference's 2-D parameter sets -- omega 1.4, fine polyDeg
     // 4-6 -- diverge under colour classes and contract under a sweep); 3-D clouds keep the colour
     // classes (K = 50 Dirichlet hierarchies contract alike under both, the sweep order costs 4x there)
-    int point_order = point_colouring_ >= 0 ? point_colouring_ : (dim_ >= 3 ? 1 : 2);
-    if (point_colouring_ < 0 && point_order == 2 && n < default_sweep_min_points) point_order = 1;  // experiment: colours on small grids
+    const int point_order = resolve_point_order();
     par_for(nt, nth, [&](int t) {
         const int b = bounds[(size_t)t], e = bounds[(size_t)t + 1], m = e - b;
         vector<vector<int>> ladj((size_t)m);
@@ -370,7 +377,48 @@ void Grid::mc_order_points(int tile_points)
             }
             return used;
         };
-        if (point_order == 2) {
+        if (point_order == 3) {
+            // ROWS ascending, colours along a row: the points of the tile are binned into rows by y (bin height 0.85 x the
+            // tile's mean spacing), inside a row ranked by x and given the colour rank mod 4; order = (row, colour, x).
+            // The sweep across the rows is what the over-relaxed smoother needs (global row sweeps with 3-8
+            // colours along the row contract like the lexicographic order, Dirichlet 0.43-0.45, Neumann 0.73-0.88), and
+            // points of one colour in one row are ~4 spacings apart, i.e. (nearly) uncoupled: a dependency level holds
+            // a quarter of a row instead of ~4 points, the depth of a tile is 4 x rows instead of ~5 sqrt(T).
+            double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300};
+            int mi = 0;
+            for (int k = 0; k < m; ++k)
+                if (relaxed[(size_t)k]) {
+                    const Point &p = points_[(size_t)idx[(size_t)(b + k)]];
+                    lo[0] = std::min(lo[0], std::get<0>(p)); hi[0] = std::max(hi[0], std::get<0>(p));
+                    lo[1] = std::min(lo[1], std::get<1>(p)); hi[1] = std::max(hi[1], std::get<1>(p));
+                    ++mi;
+                }
+            const double hest = mi > 1 ? std::sqrt(std::max(1e-300, (hi[0] - lo[0]) * (hi[1] - lo[1])) / mi) : 1.0;
+            const double binh = std::max(1e-300, 0.85 * hest);
+            vector<int> ord;
+            vector<int> rowbin((size_t)m, 0);
+            for (int k = 0; k < m; ++k)
+                if (relaxed[(size_t)k]) {
+                    ord.push_back(k);
+                    rowbin[(size_t)k] = (int)std::floor((std::get<1>(points_[(size_t)idx[(size_t)(b + k)]]) - lo[1]) / binh);
+                }
+            auto xof = [&](int k) { return std::get<0>(points_[(size_t)idx[(size_t)(b + k)]]); };
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+                if (rowbin[(size_t)x] != rowbin[(size_t)y]) return rowbin[(size_t)x] < rowbin[(size_t)y];
+                return xof(x) < xof(y);
+            });
+            vector<int> cl((size_t)m, 0);
+            for (size_t q = 0, r0 = 0; q < ord.size(); ++q) {
+                if (q > 0 && rowbin[(size_t)ord[q]] != rowbin[(size_t)ord[q - 1]]) r0 = q;
+                cl[(size_t)ord[q]] = (int)((q - r0) % 4);
+            }
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+                if (rowbin[(size_t)x] != rowbin[(size_t)y]) return rowbin[(size_t)x] < rowbin[(size_t)y];
+                if (cl[(size_t)x] != cl[(size_t)y]) return cl[(size_t)x] < cl[(size_t)y];
+                return xof(x) < xof(y);
+            });
+            for (size_t r = 0; r < ord.size(); ++r) col[(size_t)ord[r]] = (int)r;
+        } else if (point_order == 2) {
             // SWEEP order inside the tile: the points keep a lexicographic (z, y, x) order instead of colour classes.
             // Over-relaxed point SOR (the reference's omega = 1.4) is a good smoother only in a directional sweep
             // such as the reference's RCM order (grid.cpp:713-776); with colour classes the reference's V-cycle
@@ -457,7 +505,7 @@ void Grid::mc_order_points(int tile_points)
     // (DESIGN section 2c): with coloured tiles it contracts 0.90 at 256 points per tile and grows x 1.05 at 128 or 512,
     // with the tile sweep 0.94-0.96 (polyDeg 4) / 0.59-0.66 (polyDeg 6) at every tile size tried; the price is
     // ~3 sqrt(tiles) wavefront phases instead of 4.  Everything else keeps the coloured tiles.
-    const int tile_order = tile_order_ >= 0 ? tile_order_ : ((dim_ < 3 && neumannFlag_ && point_order == 2) ? 1 : 0);
+    const int tile_order = tile_order_ >= 0 ? tile_order_ : ((dim_ < 3 && neumannFlag_ && point_order >= 2) ? 1 : 0);
     if (tile_order == 0)
         std::stable_sort(torder.begin(), torder.end(), [&](int a, int b) { return tcol[(size_t)a] < tcol[(size_t)b]; });
     else
