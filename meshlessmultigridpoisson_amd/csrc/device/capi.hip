@@ -2383,7 +2383,7 @@ int mmg_fracstep_residual(mmg_fracstep *fs, double *value)
     if (fs->p->distributed && g_rccl.comm && g_rccl.nranks > 1) {
         if (fs->scal2.n == 0) HIPC(fs->scal2.alloc(2));
         HIPC(hipMemcpyAsync(fs->scal2.p, fs->scal.p, sizeof(double), hipMemcpyDeviceToDevice, g_stream));
-        HIPC(hipMemcpyAsync(fs->scal2.p + 1, &cnt, sizeof(double), hipMemcpyHostToDevice, g_stream));
+        HIPC(launch_fill(fs->scal2.p + 1, 1, cnt, g_stream));
         if (int rc = allreduce_sum(fs->scal2.p, 2)) return rc;
         double hv[2] = {0, 0};
         HIPC(hipMemcpyAsync(hv, fs->scal2.p, sizeof(hv), hipMemcpyDeviceToHost, g_stream));
