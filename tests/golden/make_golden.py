@@ -87,6 +87,17 @@ def build(sizes, polys, neumann, bvalue_fn=None, seed=12345):
     return grids, R, P
 
 
+def build_live(sizes, polys):
+    """The reference's live parameter set (run_tests / run_frac_step_test: Neumann, fine polyDeg 4-6, coarse 3) on
+    Gmsh-like clouds (setup_oracle.quasi_uniform_square_cloud), the reference's RCM order."""
+    grids = []
+    for i, (ns, pd) in enumerate(zip(sizes, polys)):
+        pts = so.quasi_uniform_square_cloud(ns)
+        grids.append(so.gen_grid_neumann_square(pts, so.make_props(pd), coarse=(i != len(sizes) - 1)))
+    R, P = so.build_matrices(grids)
+    return grids, R, P
+
+
 def ref_utils_fixture():
     """Outputs of the REFERENCE's own leaf functions (oracle/_ref)."""
     L = oc.ref_lib()
@@ -163,3 +174,6 @@ if __name__ == "__main__":
     pack_case("neumann_3level", g, R, P)
     g, R, P = build([13, 25], [3, 3], neumann=False, bvalue_fn=lambda x, y: 1.0 + x + 2 * y)
     pack_case("dirichlet_2level_inhomog", g, R, P)
+    if "--live" in sys.argv or not os.path.exists(os.path.join(OUT, "neumann_live_L6_3level.npz")):
+        g, R, P = build_live([13, 25, 49], [3, 3, 6])       # O(N^2) python setup with 98 x 98 solves: a few minutes
+        pack_case("neumann_live_L6_3level", g, R, P)

@@ -20,7 +20,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["dirichlet_3level", "neumann_2level", "neumann_3level", "dirichlet_2level_inhomog"]
+CASES = ["dirichlet_3level", "neumann_2level", "neumann_3level", "dirichlet_2level_inhomog", "neumann_live_L6_3level"]
 
 
 def _need_gpu():
@@ -79,7 +79,11 @@ def test_dense_multiwave_kernels_match_oracle(name, tile, L, waves, mode):
     _capi.set_option("persistent_sweep", mode)
     try:
         d = H.device_level(la, tile_size=tile, lanes_per_row=L, waves_per_tile=waves)
-        assert d.info()["waves_per_tile"] == waves
+        rowlen = int(np.diff(la["rowptr"])[:-1 if la["neumann"] else None][la["bcflags"] == 0].max())
+        if rowlen - 2 <= 8 * L:
+            assert d.info()["waves_per_tile"] == waves
+        else:   # the polyDeg-6 Neumann fixture: rows of ~190 entries take several row slots (4 / 6 wavefronts) or the packed stream
+            assert d.info()["waves_per_tile"] in (1, 4, 6)
         o.boundary_op(0)
         d.boundary_op(0)
         o.sor_sweeps(1)
@@ -115,7 +119,7 @@ def test_vcycle_residual_history_dense_levels(name):
         assert all(l.info()["waves_per_tile"] == 4 for l in dh.levels)
         for k in range(len(case["resid_history"])):
             ro, rd = om.vcycle(), dh.vcycle()
-            assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+            assert abs(rd - ro) <= 1e-10 * ro + max(FLOOR, H.rho_evaluation_noise(om.levels[-1])), (k, rd, ro)
         assert H.rel_err(dh.levels[-1].get_x(), om.levels[-1].x) < 1e-9
         # every coarser level too (round-2 review, weak 10).  A coarse level holds the CORRECTION of the last cycle, of
         # the size of the converged residual: the comparison is absolute, against the scale of the finest iterate --
@@ -215,8 +219,9 @@ def test_vcycle_residual_history(name, sweep_mode):
     for k in range(len(gold)):
         ro = om.vcycle()
         rd = dh.vcycle()
-        assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
-        assert abs(rd - gold[k]) <= 1e-10 * gold[k] + FLOOR, (k, rd, gold[k])
+        floor = max(FLOOR, H.rho_evaluation_noise(om.levels[-1]))   # 2e-13 on the small fixtures, ~1e-12 at polyDeg 6
+        assert abs(rd - ro) <= 1e-10 * ro + floor, (k, rd, ro)
+        assert abs(rd - gold[k]) <= 1e-10 * gold[k] + floor, (k, rd, gold[k])
     assert abs(dh.residual() - om.residual()) <= 1e-10 * om.residual() + 1e-13
     xo = om.levels[-1].x
     assert np.abs(dh.levels[-1].get_x() - xo).max() <= 1e-9 * np.abs(xo).max()
@@ -605,7 +610,7 @@ def test_distributed_code_path_single_rank(name):
             lv.set_exchange(lv.n, [], [0], [], [0])
         for k in range(8):
             ro, rd = om.vcycle(), dh.vcycle()
-            assert abs(rd - ro) <= 1e-10 * ro + FLOOR, (k, rd, ro)
+            assert abs(rd - ro) <= 1e-10 * ro + max(FLOOR, H.rho_evaluation_noise(om.levels[-1])), (k, rd, ro)
         assert H.rel_err(dh.levels[-1].get_x(), om.levels[-1].x) < 1e-9
     finally:
         _capi.comm_finalize()

@@ -5,7 +5,7 @@ import pytest
 
 from tests import helpers as H
 
-CASES = ["dirichlet_3level", "neumann_2level", "neumann_3level", "dirichlet_2level_inhomog"]
+CASES = ["dirichlet_3level", "neumann_2level", "neumann_3level", "dirichlet_2level_inhomog", "neumann_live_L6_3level"]
 
 
 @pytest.mark.parametrize("name", CASES)
