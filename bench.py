@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N>1: weak = --nside^dim points per rank; strong = one --total-nside^dim cloud shared by all ranks")
     ap.add_argument("--total-nside", type=int, default=342, help="--scaling strong: points per axis of the whole cloud")
+    ap.add_argument("--partition", choices=("slab", "box"), default="slab",
+                    help="N>1: x-slabs (default) or boxes, as cubic as possible (8 ranks: 2 x 2 x 2, SURVEY 8d's decomposition of "
+                         "configs[3]; fewer ghost values per rank in strong scaling, up to 7 neighbours instead of 2)")
     ap.add_argument("--no-vcycle", action="store_true", help="skip the whole-V-cycle legs")
     ap.add_argument("--dd-vcycle-nside", type=int, default=128,
                     help="N>1: points per axis of the ONE cloud of the distributed V-cycle leg (every rank builds the global hierarchy)")
@@ -399,7 +402,9 @@ def main():
         cus, lds = 0, 0
     dd = world > 1 or a.force_dd
     strong = dd and a.scaling == "strong"
-    if strong:
+    if strong and a.partition == "box":
+        pts_per_rank = a.total_nside ** a.dim // max(world, 1)
+    elif strong:
         lo_x, hi_x = _host.slab_bounds(rank, world, a.total_nside)
         pts_per_rank = (hi_x - lo_x) * a.total_nside ** (a.dim - 1)
     else:
@@ -436,10 +441,11 @@ def main():
         # margin; ghost ids are agreed on with one all_gather at setup.  weak: rank r owns layers
         # [r*nside, (r+1)*nside) of a (world*nside) x nside^(dim-1) lattice; strong: an equal share of the
         # layers of ONE total_nside^dim lattice on the unit cube
+        local_cloud = _host.block_cloud if a.partition == "box" else _host.slab_cloud
         if strong:
-            pts, flags, gid, owner = _host.slab_cloud(rank, world, a.total_nside, dim=a.dim, margin=5, total=True)
+            pts, flags, gid, owner = local_cloud(rank, world, a.total_nside, dim=a.dim, margin=5, total=True)
         else:
-            pts, flags, gid, owner = _host.slab_cloud(rank, world, a.nside, dim=a.dim, margin=5)
+            pts, flags, gid, owner = local_cloud(rank, world, a.nside, dim=a.dim, margin=5)
         grid = _host.Grid.create_local(pts, flags, gid, owner, a.dim, stencil, tile_points=a.tile, lanes_per_row=a.lanes,
                                        kind=kind, polydeg=a.polydeg)
         n_owned, lgid, gown = grid.local_map()
@@ -631,7 +637,7 @@ def main():
     if rank == 0:
         if strong:
             wl = (f"{a.dim}-D {a.total_nside}^{a.dim} = {a.total_nside ** a.dim} points in ONE cloud shared by {world} "
-                  f"GPUs (x-slabs; BASELINE configs[3] at 8 GPUs)")
+                  f"GPUs ({'x-slabs' if a.partition == 'slab' else 'boxes'}; BASELINE configs[3] at 8 GPUs)")
         else:
             wl = f"{a.dim}-D {a.nside}^{a.dim} = {n_owned} points per GPU"
         out = {
@@ -658,7 +664,7 @@ def main():
                 "lds_bytes_per_wave": info["max_lds_bytes"], "persistent_sweep": int(launches <= sweeps_timed), "sweeps_executed": a.warmup + a.steps + sweeps_timed + 2 * a.verify,
                 "packed_bytes_per_row": round((info["stream_bytes"] + 12 * info["halo_entries"]) / max(interior, 1) + 24, 1),
                 "parallelism": "single" if not dd else
-                               f"domain decomposition: {world} x-slabs, RCCL ghost exchange "
+                               f"domain decomposition: {world} " + ("x-slabs" if a.partition == "slab" else "boxes " + "x".join(str(v) for v in _host.block_dims(world, a.dim)[:a.dim])) + ", RCCL ghost exchange "
                                + ("once per sweep (block-hybrid Gauss-Seidel)" if a.exchange == "sweep" else
                                   "before every phase (exact sequential Gauss-Seidel on the global system)")
                                + f", {sz['n'] - n_owned} ghost values per rank",

@@ -890,3 +890,62 @@ def slab_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25, to
     owner = (np.searchsorted(starts, idx[:, 0], side="right") - 1).astype(np.int32)
     flags = np.where(owner == rank, bnd.astype(np.int32), 3).astype(np.int32)
     return pts, flags, gid.astype(np.int32), owner
+
+
+def block_dims(nranks, dim=3):
+    """Ranks per axis of the box decomposition: as cubic as possible (8 -> 2 x 2 x 2, 4 -> 2 x 2 x 1, 6 -> 3 x 2 x 1,
+    a prime count -> slabs)."""
+    dims = [1] * 3
+    n = int(nranks)
+    f = 2
+    factors = []
+    while n > 1:
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+        f += 1
+    for f in sorted(factors, reverse=True):
+        a = min(range(dim), key=lambda k: dims[k])
+        dims[a] *= f
+    dims[:dim] = sorted(dims[:dim], reverse=True)
+    return tuple(dims)
+
+
+def block_cloud(rank, nranks, nside, dim=3, margin=5, seed=12345, jitter=0.25, total=False):
+    """Rank's part of a jittered lattice cut into BOXES (configs[3] names 2 x 2 x 2 sub-domains): its own
+    block of lattice points plus `margin` layers around it (faces, edges and corners) as ghost candidates.  Ranks per
+    axis from block_dims.  total = False (weak scaling): every rank owns nside^dim points of a (px nside) x (py nside)
+    x (pz nside) lattice; total = True (strong scaling): ONE nside^dim lattice on the unit cube shared by the boxes.
+    Same return convention and the same jitter (a hash of the global id) as slab_cloud."""
+    p = block_dims(nranks, dim)
+    nglob = [nside if total else p[a] * nside for a in range(3)]
+    if dim == 2:
+        nglob[2] = 1
+    h = 1.0 / (nside - 1)
+    b = [rank % p[0], (rank // p[0]) % p[1], rank // (p[0] * p[1])]
+    rng_ax, own = [], []
+    for a in range(3):
+        if a >= dim:
+            rng_ax.append(np.arange(1))
+            own.append((0, 1))
+            continue
+        lo, hi = slab_bounds(b[a], p[a], nglob[a])
+        own.append((lo, hi))
+        rng_ax.append(np.arange(max(0, lo - margin), min(nglob[a], hi + margin)))
+    IZ, IY, IX = np.meshgrid(rng_ax[2], rng_ax[1], rng_ax[0], indexing="ij")
+    idx = np.stack([IX.ravel(), IY.ravel(), IZ.ravel()], axis=1)
+    gid = (idx[:, 2] * nglob[1] + idx[:, 1]) * nglob[0] + idx[:, 0]
+    pts = idx.astype(np.float64) * h
+    bnd = np.zeros(len(idx), dtype=bool)
+    for a in range(dim):
+        bnd |= (idx[:, a] == 0) | (idx[:, a] == nglob[a] - 1)
+    for a in range(dim):
+        pts[~bnd, a] += _jitter_hash(gid[~bnd], a, seed) * jitter * h
+    owner = np.zeros(len(idx), dtype=np.int64)
+    mult = [1, p[0], p[0] * p[1]]
+    for a in range(dim):
+        starts = np.array([slab_bounds(r, p[a], nglob[a])[0] for r in range(p[a])])
+        owner += mult[a] * (np.searchsorted(starts, idx[:, a], side="right") - 1)
+    owner = owner.astype(np.int32)
+    flags = np.where(owner == rank, bnd.astype(np.int32), 3).astype(np.int32)
+    return pts, flags, gid.astype(np.int32), owner

@@ -90,15 +90,18 @@ def test_subdomains_hybrid_schedule_matches_oracle(nparts):
     _check_against_oracle(la, part, nparts, [(maps[r][0], maps[r][1], levels[r][0].x) for r in range(nparts)], nsweeps)
 
 
-def test_slab_cloud_local_systems_are_consistent():
-    """Weak-scaling path: every rank builds its own part from its owned lattice layers plus
-    a margin, without a global system.  Gluing the local matrices together must give one
-    consistent global operator, and the hybrid schedule on it must match the oracle."""
+@pytest.mark.parametrize("gen,nr,nside,total", [("slab", 2, 14, False), ("box", 4, 10, False), ("box", 8, 20, True)])
+def test_slab_cloud_local_systems_are_consistent(gen, nr, nside, total):
+    """Slab-local / box-local path (what bench.py --gpus N uses): every rank builds its own part from its owned lattice
+    points plus a margin, without a global system.  Gluing the local matrices together must give one consistent
+    global operator, and the hybrid schedule on it must match the oracle.  Boxes: 2 x 2 x 1 (weak) and 2 x 2 x 2 of ONE
+    cloud (strong: BASELINE configs[3]'s decomposition)."""
     from meshlessmultigridpoisson_amd import _host as host
-    nr, nside, dim, K = 2, 14, 3, 50
+    dim, K = 3, 50
+    cloud = host.slab_cloud if gen == "slab" else host.block_cloud
     subs, maps = [], []
     for r in range(nr):
-        pts, flags, gid, owner = host.slab_cloud(r, nr, nside, dim=dim, margin=5)
+        pts, flags, gid, owner = cloud(r, nr, nside, dim=dim, margin=5, total=total)
         s = host.Grid.create_local(pts, flags, gid, owner, dim, K, tile_points=256, lanes_per_row=2)
         subs.append(s)
         maps.append(s.local_map())
@@ -113,7 +116,7 @@ def test_slab_cloud_local_systems_are_consistent():
     for r, (no, gid, _) in enumerate(maps):
         for k in range(no):
             gid2glob[int(gid[k])] = int(offs[r] + k)
-    assert len(gid2glob) == nr * nside ** 3
+    assert len(gid2glob) == (nside ** 3 if total else nr * nside ** 3)
     rowptr, col, val, flags_g, part = [0], [], [], np.zeros(ntot, dtype=np.int32), np.zeros(ntot, dtype=np.int32)
     bpts = []
     for r, s in enumerate(subs):
