@@ -236,7 +236,10 @@ void Grid::mc_order_points(int tile_points)
         // sub-domains (x-slab partitions): an even number of x-slabs per rank makes the tiles on
         // either side of a cut differ in x-parity, hence in colour -- what the exact (per-phase)
         // ghost exchange needs (mmg_level_set_exchange_mode)
-        if (nOwned_ >= 0 && (m[0] & 1)) m[0]++;
+        // (box partitions are cut in y and z as well: an even tile count along every axis)
+        if (nOwned_ >= 0)
+            for (int a2 = 0; a2 < dim_; ++a2)
+                if (m[a2] & 1) m[a2]++;
         auto cut = [](int lo, int hi, int parts, int k) { return lo + (int)((long long)(hi - lo) * k / parts); };
         sort_by_axis(points_, idx, 0, n_t, 0, nth);
         vector<std::pair<int, int>> slabs;

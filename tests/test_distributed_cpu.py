@@ -599,10 +599,10 @@ def test_slab_cloud_rbf_rows_reproduce_polynomials_across_the_cut():
 
 
 # ---- exact (per-phase) exchange: the distributed sweep IS the sequential reference sweep -----
-def _slab_ranks(host, nr, nside, dim, K, kind=None):
+def _slab_ranks(host, nr, nside, dim, K, kind=None, gen="slab"):
     subs, maps = [], []
     for r in range(nr):
-        pts, flags, gid, owner = host.slab_cloud(r, nr, nside, dim=dim, margin=5)
+        pts, flags, gid, owner = (host.slab_cloud if gen == "slab" else host.block_cloud)(r, nr, nside, dim=dim, margin=5)
         kw = {} if kind is None else dict(kind=kind, polydeg=3)
         s = host.Grid.create_local(pts, flags, gid, owner, dim, K, tile_points=256, lanes_per_row=2, **kw)
         subs.append(s)
@@ -624,7 +624,7 @@ def _exchange_vecs(levels, maps, lists, vecs):
 
 
 @pytest.mark.parametrize("nr", [2, 3])
-def test_per_phase_exchange_is_sequential_gauss_seidel(nr):
+def test_per_phase_exchange_is_sequential_gauss_seidel(nr, gen="slab"):
     """mmg_level_set_exchange_mode(per_phase = 1): ghosts refreshed before every phase.  The ranks'
     iterates must then be those of the reference's sequential row loop (grid.cpp:112-145, restated by
     the plain oracle -- NOT the hybrid one) on the glued global system in the storage order
@@ -632,7 +632,7 @@ def test_per_phase_exchange_is_sequential_gauss_seidel(nr):
     map and the conflict test are the library's own (level_plan.cpp:level_point_phases)."""
     from meshlessmultigridpoisson_amd import _host as host
     nside, dim, K = 12, 3, 50
-    subs, maps, lists = _slab_ranks(host, nr, nside, dim, K)
+    subs, maps, lists = _slab_ranks(host, nr, nside, dim, K, gen=gen)
     emus, las = zip(*[_local_level(s) for s in subs])
     phases, masks = zip(*[e.point_phases() for e in emus])
     # what the collective check of mmg_level_set_exchange_mode does: owner's phase of every ghost
@@ -937,3 +937,10 @@ def test_rcb_boxes_need_fewer_ghosts_than_slabs_in_3d():
             tot += len(gid) - no
         ghosts[kind] = tot
     assert ghosts[1] < 0.8 * ghosts[0], ghosts
+
+
+def test_per_phase_exchange_with_box_partition():
+    """The exact (per-phase) exchange mode on 2 x 2 x 1 BOXES: the tile counts of a sub-domain are even along every axis,
+    so the tile colours differ across the cuts in x AND in y (and across the corner between diagonal neighbours) -- the
+    ranks' iterates are again the reference's sequential sweep on the glued global system."""
+    test_per_phase_exchange_is_sequential_gauss_seidel(4, gen="box")
