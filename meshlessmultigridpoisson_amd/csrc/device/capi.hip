@@ -682,7 +682,8 @@ int residual_dev(mmg_level *lv, bool norms)
         c.partial = lv->partB.p;
         HIPC(run_tiles(lv->B, MODE_RESID, c, g_stream));
     }
-    HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
+    if (!a.resid_lds)  // with the LDS write-back the tile kernel has written the zeros of the Dirichlet rows itself
+        HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
     if (norms) HIPC(launch_abs_sum(lv->b.p, lv->a_size, lv->partBn.p, g_stream));
     if (lv->distributed && lv->neumann) {
         HIPC(launch_sum_partials(lv->partX.p, lv->A.n_tiles, lv->scalS.p, g_stream));

@@ -392,9 +392,10 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 #endif
     if (MODE == MODE_RESID) {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
-        // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan (residual_dev)
+        // overwrites the Neumann rows from the boundary plan (residual_dev); Dirichlet rows are written as zeros here
         if (a.resid_lds)
-            for (uint32_t i = lane; i < n_own; i += 64) a.out[td.row0 + i] = bs[i];
+            for (uint32_t i = lane; i < n_own; i += 64)
+                a.out[td.row0 + i] = (a.flags8 && a.flags8[td.row0 + i] == 1) ? 0.0 : bs[i];
         if (a.partial) {
             local = wave_sum(local);
             if (lane == 0) a.partial[tile] = local;

@@ -282,9 +282,10 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         }
     } else {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
-        // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan
+        // overwrites the Neumann rows from the boundary plan; Dirichlet rows are written as zeros here
         if (a.resid_lds)
-            for (uint32_t i = tid; i < n_own; i += NT) a.out[td.row0 + i] = bs[i];
+            for (uint32_t i = tid; i < n_own; i += NT)
+                a.out[td.row0 + i] = (a.flags8 && a.flags8[td.row0 + i] == 1) ? 0.0 : bs[i];
         if (a.partial) {
             local = wave_sum(local);
             if (lane == 0) red[wave] = local;

@@ -77,6 +77,7 @@ Grid::Grid(vector<Point> points, vector<Boundary> boundaries, GridProperties pro
     device_setup_ = default_device_setup;
     point_colouring_ = default_point_colouring;
     tile_order_ = default_tile_order;
+    tile_fronts_ = default_tile_fronts;
     if (default_mult_row > 0.0) multRow_ = default_mult_row;
 }
 
@@ -348,6 +349,7 @@ double Grid::default_mult_row = 0.0;
 int Grid::default_device_setup = -1;
 int Grid::default_point_colouring = -1;
 int Grid::default_tile_order = -1;
+int Grid::default_tile_fronts = 1;
 int Grid::default_sweep_min_points = 0;
 
 bool Grid::batched_stencils(const vector<Point> &evals, const vector<char> *evalIsBoundary, bool neumann, int polyDeg,

@@ -79,6 +79,10 @@ public:
                                  // (4 / 8 phases), 1 lexicographic sweep over the tiles (wavefront phases)
     static int default_sweep_min_points;  // mmgh_set_option "sweep_min_points": automatic point order uses colour classes below this size
     static int default_tile_order;       // mmgh_set_option "tile_order"
+    int tile_fronts_ = 1;        // point order 2: the tile is swept by this many fronts at once (y-bands of equal point count,
+                                 // band-local lexicographic rank r of band c gets the position r * fronts + c): the dependency
+                                 // depth of a tile drops from ~w + 4h to ~w + 4h / fronts levels (w x h points)
+    static int default_tile_fronts;      // mmgh_set_option "tile_fronts"
     int setup_threads_ = 0;      // 0 = hardware concurrency
     // Dense stencil solves of the setup (laplaceWeights / pointInterpWeights / deriv*_weights):
     // -1 automatic (batched on the MI355X through mmg_rbf_weights when a device is present and

@@ -874,6 +874,7 @@ int mmgh_set_option(const char *name, int value)
     if (name && std::string(name) == "device_setup") { Grid::default_device_setup = value; return 0; }
     if (name && std::string(name) == "point_colouring") { Grid::default_point_colouring = value; return 0; }
     if (name && std::string(name) == "tile_order") { Grid::default_tile_order = value; return 0; }
+    if (name && std::string(name) == "tile_fronts") { Grid::default_tile_fronts = value < 1 ? 1 : value; return 0; }
     if (name && std::string(name) == "partition") { Grid::default_partition = value; return 0; }
     if (name && std::string(name) == "sweep_min_points") { Grid::default_sweep_min_points = value; return 0; }
     if (name && std::string(name) == "multiplier_row_ppm") { Grid::default_mult_row = value / 1.0e6; return 0; }

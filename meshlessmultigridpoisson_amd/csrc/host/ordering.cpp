@@ -436,7 +436,15 @@ void Grid::mc_order_points(int tile_points)
                 if (std::get<1>(px) != std::get<1>(py)) return std::get<1>(px) < std::get<1>(py);
                 return std::get<0>(px) < std::get<0>(py);
             });
-            for (int r = 0; r < m; ++r) col[(size_t)ord[(size_t)r]] = r;
+            const int F = std::max(1, std::min(tile_fronts_, m / 32));
+            if (F == 1) {
+                for (int r = 0; r < m; ++r) col[(size_t)ord[(size_t)r]] = r;
+            } else {
+                // several fronts: the lexicographic list is cut into F y-bands of equal count that are swept at the same
+                // time -- position r of band c is relaxed as number r * F + c of the tile
+                const int per = (m + F - 1) / F;
+                for (int r = 0; r < m; ++r) col[(size_t)ord[(size_t)r]] = (r % per) * F + r / per;
+            }
         } else if (point_order == 0 || n_t > 3000000) {  // plain greedy in tile order (round 1; bandwidth-bound levels: the chain is hidden)
             for (int k = 0; k < m; ++k)
                 if (relaxed[(size_t)k]) order.push_back(k);
