@@ -274,6 +274,14 @@ void emu_set_dense_xtra(int v) { mmg::g_dense_xtra_enabled = v; }
 int emu_level_dense_xtra(void *h) { return static_cast<Emu *>(h)->A.dense_xtra ? 1 : 0; }
 long long emu_level_stream_bytes(void *h) { return (long long)static_cast<Emu *>(h)->A.stream.size(); }
 long long emu_level_nnz(void *h) { return static_cast<Emu *>(h)->A.n_nnz; }
+// per tile: groups, rows, phase (balance diagnostics of the tiling)
+void emu_level_tile_stats(void *h, int *groups, int *rows, int *phase)
+{
+    const Emu *e = static_cast<Emu *>(h);
+    for (int t = 0; t < e->A.n_tiles; ++t) { groups[t] = (int)e->A.tiles[(size_t)t].n_groups; rows[t] = (int)e->A.tiles[(size_t)t].n_rows; }
+    for (int p = 0; p < e->A.n_phases(); ++p)
+        for (int k = e->A.phase_ptr[(size_t)p]; k < e->A.phase_ptr[(size_t)p + 1]; ++k) phase[e->A.phase_tiles[(size_t)k]] = p;
+}
 
 void emu_level_bound_eval(void *h, double *x, const double *b)
 {
