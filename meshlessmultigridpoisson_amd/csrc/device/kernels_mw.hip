@@ -146,34 +146,52 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     const double *in = a.in;
     const int32_t *hl = a.p.halo + td.halo_off;
     {
-        constexpr int HB = 4;  // halo values per thread and pass: indices first, then the values, all in flight
+        // halo values per thread and pass: indices first, then the values, all in flight (a lone wavefront has the
+        // registers for 16: the ~800 halo points of a 505-point 2-D tile in one pass instead of four)
+        constexpr int HB = NW == 1 ? 16 : (NW == 2 ? 8 : 4);
         int32_t ti[HB];
         if (n_halo > 0) {
 #pragma unroll
             for (int k = 0; k < HB; ++k) {
                 const uint32_t i = k * NT + tid;
-                ti[k] = hl[i < n_halo ? i : n_halo - 1];
+                if ((uint32_t)(k * NT) < n_halo) ti[k] = hl[i < n_halo ? i : n_halo - 1];   // (workgroup-uniform guard)
             }
         }
-        if (!keep_own)
-            for (uint32_t i = tid; i < n_own; i += NT) bs[i] = a.b[td.row0 + i];
+        // own range: HB values per thread requested together (a plain `for (i = tid; ...) xs[i] = load` is one memory
+        // round trip per iteration -- eight in a row for a 505-point tile of one wavefront)
+        auto stage_own = [&](auto load, double *dst) {
+            for (uint32_t base = 0; base < n_own; base += NT * HB) {
+                double tv[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const uint32_t i = base + k * NT + tid;
+                    if (base + k * NT < n_own) tv[k] = load(td.row0 + (i < n_own ? i : n_own - 1));   // (workgroup-uniform guard)
+                }
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                    const uint32_t i = base + k * NT + tid;
+                    if (i < n_own) dst[i] = tv[k];
+                }
+            }
+        };
+        if (!keep_own) stage_own([&](uint32_t i) { return a.b[i]; }, bs);
         if (!gate()) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the requests above land in registers of this frame
             return;
         }
-        if (!keep_own)
-            for (uint32_t i = tid; i < n_own; i += NT) xs[i] = ld_x<SC1>(in + td.row0 + i);
+        if (!keep_own) stage_own([&](uint32_t i) { return ld_x<SC1>(in + i); }, xs);
         for (uint32_t base = 0; base < n_halo; base += NT * HB) {
             if (base > 0) {
 #pragma unroll
                 for (int k = 0; k < HB; ++k) {
                     const uint32_t i = base + k * NT + tid;
-                    ti[k] = hl[i < n_halo ? i : n_halo - 1];
+                    if (base + k * NT < n_halo) ti[k] = hl[i < n_halo ? i : n_halo - 1];
                 }
             }
             double tx[HB];
 #pragma unroll
-            for (int k = 0; k < HB; ++k) tx[k] = ld_x<SC1>(in + ti[k]);
+            for (int k = 0; k < HB; ++k)
+                if (base + k * NT < n_halo) tx[k] = ld_x<SC1>(in + ti[k]);
 #pragma unroll
             for (int k = 0; k < HB; ++k) {
                 const uint32_t i = base + k * NT + tid;
