@@ -33,6 +33,8 @@ bool g_exact = false;  // mmg_set_option("exact_arithmetic", 1): plans created a
 // prefetch it had just issued (see kernels.hip, group loop) they measured 4-5 % slower; with the join-free loop the
 // sweep is byte-bound again and they are 4-5 % faster (same box, 1e7 points, T = 1280: 81.3 / 81.4 vs 76.6 %).
 int g_slot_bits = 12;
+int g_dense_single_lanes = 0;  // mmg_set_option("dense_single_lanes", 0 | 8 | 16): lanes per row of the one-wavefront dense layout (0: automatic)
+int g_max_workers = 0;  // mmg_set_option("max_workers", n): cap on the workgroups of the dependency-driven sweep kernels (0: occupancy x CUs); A/B aid
 int g_resid_lds = 1;  // mmg_set_option("resid_lds", 0 | 1): residual rows leave a tile through LDS, coalesced
 int g_lds_resident = 1;  // mmg_set_option("lds_resident", 0 | 1): LDS-resident tile streams for the phases of small levels
 int g_persistent_sweep = 1;  // mmg_set_option("persistent_sweep", ...): 0 never, 1 auto (default), 2 always + fences, 4 always
@@ -682,8 +684,7 @@ int residual_dev(mmg_level *lv, bool norms)
         c.partial = lv->partB.p;
         HIPC(run_tiles(lv->B, MODE_RESID, c, g_stream));
     }
-    if (!a.resid_lds)  // with the LDS write-back the tile kernel has written the zeros of the Dirichlet rows itself
-        HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
+    HIPC(launch_scatter_const(lv->r.p, lv->dir_idx.p, (int)lv->dir_idx.n, 0.0, g_stream));
     if (norms) HIPC(launch_abs_sum(lv->b.p, lv->a_size, lv->partBn.p, g_stream));
     if (lv->distributed && lv->neumann) {
         HIPC(launch_sum_partials(lv->partX.p, lv->A.n_tiles, lv->scalS.p, g_stream));
@@ -1032,6 +1033,8 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "slot_bits") == 0) { g_slot_bits = value == 12 ? 12 : 16; return MMG_OK; }
     if (std::strcmp(name, "lds_resident") == 0) { g_lds_resident = value; return MMG_OK; }
     if (std::strcmp(name, "resid_lds") == 0) { g_resid_lds = value != 0; return MMG_OK; }
+    if (std::strcmp(name, "max_workers") == 0) { g_max_workers = value > 0 ? value : 0; return MMG_OK; }
+    if (std::strcmp(name, "dense_single_lanes") == 0) { g_dense_single_lanes = (value == 8 || value == 16) ? value : 0; return MMG_OK; }
     if (std::strcmp(name, "waves_per_tile") == 0) { g_waves = value; return MMG_OK; }
     if (std::strcmp(name, "debug_spin_bound") == 0) { g_spin_bound = value < 0 ? (1 << 22) : value; return MMG_OK; }
     if (std::strcmp(name, "debug_fail_graph") == 0) { g_debug_fail_graph = value; return MMG_OK; }
@@ -1258,9 +1261,12 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
             (double)P.n_rows < 0.4 * (double)P.n_groups * (64 / P.L)) {
             Plan P1;
             mmg_level_desc d1 = dd;
-            d1.lanes_per_row = 8;
-            if (build_level_plan(d1, L, &P1, false, g_slot_bits, -1).empty() && P1.dense && P1.waves == 1 && P1.L == 8 &&
-                P1.dense_plen <= 5)
+            // K = 37 (5 entries on 8 lanes): 16 lanes x 3 entries -- rounds of 4 rows instead of 8 are nearly full
+            // (583 instead of 755 B per row at 27 % more rounds); K = 25 fills 8 lanes x 3 entries exactly
+            const int lanes1 = g_dense_single_lanes > 0 ? g_dense_single_lanes : 8;
+            d1.lanes_per_row = lanes1;
+            if (build_level_plan(d1, L, &P1, false, g_slot_bits, -1).empty() && P1.dense && P1.waves == 1 && P1.L == lanes1 &&
+                (lanes1 == 16 ? P1.dense_plen == 3 : P1.dense_plen <= 5))
                 P = std::move(P1);
         }
         lv->A.exact = g_exact;
@@ -1305,6 +1311,7 @@ int mmg_level_create(mmg_level **out, const mmg_level_desc *d)
         else
         HIPC(sweep_persistent_blocks_per_cu(lv->A.dev, &per_cu));
         lv->workers = per_cu * prop.multiProcessorCount;
+        if (g_max_workers > 0) lv->workers = std::min(lv->workers, g_max_workers);
     }
     HIPC(hipMemset(lv->partA.p, 0, sizeof(double) * lv->partA.n));
     HIPC(hipMemset(lv->partX.p, 0, sizeof(double) * lv->partX.n));

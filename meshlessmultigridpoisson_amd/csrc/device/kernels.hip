@@ -375,13 +375,13 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
     if (dbt) g_dbg_tiles[tile * 4 + 2] = wall_clock64();
 #endif
     if (MODE == MODE_SOR) {
-        double s = 0.0;
-        for (uint32_t i = lane; i < n_own; i += 64) {
-            const double v = xs[i];
-            st_x<SC1>(a.out + td.row0 + i, v);
-            if (a.partial && a.flags8[td.row0 + i] < 2) s += v;
-        }
+        // (stores only -- see process_tile_mw: flag loads in this loop make the compiler drain vmcnt, i.e. the previous
+        // store, before every store)
+        for (uint32_t i = lane; i < n_own; i += 64) st_x<SC1>(a.out + td.row0 + i, xs[i]);
         if (a.partial) {
+            double s = 0.0;
+            for (uint32_t i = lane; i < n_own; i += 64)
+                if (a.flags8[td.row0 + i] < 2) s += xs[i];
             s = wave_sum(s);
             if (lane == 0) a.partial[tile] = s;
         }
@@ -392,10 +392,9 @@ __device__ __forceinline__ void process_tile(const TileArgs &a, const int tile, 
 #endif
     if (MODE == MODE_RESID) {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
-        // overwrites the Neumann rows from the boundary plan (residual_dev); Dirichlet rows are written as zeros here
+        // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan (residual_dev)
         if (a.resid_lds)
-            for (uint32_t i = lane; i < n_own; i += 64)
-                a.out[td.row0 + i] = (a.flags8 && a.flags8[td.row0 + i] == 1) ? 0.0 : bs[i];
+            for (uint32_t i = lane; i < n_own; i += 64) a.out[td.row0 + i] = bs[i];   // (stores only: no vmcnt wait between them)
         if (a.partial) {
             local = wave_sum(local);
             if (lane == 0) a.partial[tile] = local;

@@ -299,13 +299,13 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     if (!kInPlace) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // bs[] complete (resid_lds)
 
     if (MODE == MODE_SOR) {
-        double s = 0.0;
-        for (uint32_t i = tid; i < n_own; i += NT) {
-            const double v = xs[i];
-            st_x<SC1>(a.out + td.row0 + i, v);
-            if (a.partial && a.flags8[td.row0 + i] < 2) s += v;
-        }
+        // (stores only: with the flag loads of the multiplier sum in the same loop the compiler waits for vmcnt(0) --
+        // i.e. for the previous iteration's STORE -- before every store: 8 stores of a 505-point tile took 3.1 us)
+        for (uint32_t i = tid; i < n_own; i += NT) st_x<SC1>(a.out + td.row0 + i, xs[i]);
         if (a.partial) {
+            double s = 0.0;
+            for (uint32_t i = tid; i < n_own; i += NT)
+                if (a.flags8[td.row0 + i] < 2) s += xs[i];
             s = wave_sum(s);
             if (lane == 0) red[wave] = s;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -317,10 +317,9 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         }
     } else {
         // own points that are no rows of this plan (boundary points) receive their rhs here; the caller
-        // overwrites the Neumann rows from the boundary plan; Dirichlet rows are written as zeros here
+        // overwrites them: Dirichlet rows are zeroed, Neumann rows come from the boundary plan
         if (a.resid_lds)
-            for (uint32_t i = tid; i < n_own; i += NT)
-                a.out[td.row0 + i] = (a.flags8 && a.flags8[td.row0 + i] == 1) ? 0.0 : bs[i];
+            for (uint32_t i = tid; i < n_own; i += NT) a.out[td.row0 + i] = bs[i];   // (stores only: no vmcnt wait between them)
         if (a.partial) {
             local = wave_sum(local);
             if (lane == 0) red[wave] = local;
@@ -496,7 +495,7 @@ hipError_t launch_mw_LP(MwKernel k, const TileArgs &a, int workers, hipStream_t 
 {
     switch (a.p.waves) {
     case 1:   // one wavefront per tile: the sweep-ordered 2-D levels (rounds of ~4 rows)
-        if constexpr (L == 8 && P <= 5) return launch_mw_LPN<L, P, 1>(k, a, workers, s, occ);
+        if constexpr ((L == 8 && P <= 5) || (L == 16 && P == 3)) return launch_mw_LPN<L, P, 1>(k, a, workers, s, occ);
         break;
     case 2: return launch_mw_LPN<L, P, 2>(k, a, workers, s, occ);
     case 3: return launch_mw_LPN<L, P, 3>(k, a, workers, s, occ);

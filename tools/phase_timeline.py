@@ -2,18 +2,19 @@
 """Development aid (needs the -DMMG_DEBUG_TIMING build: tools/build_dbg.sh, MMGP_LIBDIR=dbglib): timeline of ONE sweep
 of a small dense level -- per phase (clusters of the tiles' entry stamps) the median entry, inputs staged, rounds
 done, written back; shows what a phase costs besides its rounds.
-usage: phase_timeline.py nside neumann(0/1) [dim=3]"""
+usage: phase_timeline.py nside neumann(0/1) [dim=3] [polydeg=3]"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from meshlessmultigridpoisson_amd import _capi, _host
 ns = int(sys.argv[1]); neu = int(sys.argv[2]); dim = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+deg = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 L = _capi.lib()
 L.mmg_debug_timing_tiles.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
 _host.set_option("device_setup", 1)
 pts = _host.box_cloud(ns, dim, seed=12345, edges=not neu) if dim == 3 else _host.quasi_uniform_square_cloud(ns)
-g = _host.Grid.create_square(pts, 3, dim=dim, kind=_host.KIND_NEUMANN if neu else _host.KIND_DIRICHLET, ordering=_host.ORDER_MC, tile_points=0)
+g = _host.Grid.create_square(pts, deg, dim=dim, kind=_host.KIND_NEUMANN if neu else _host.KIND_DIRICHLET, ordering=_host.ORDER_MC, tile_points=0)
 sz = g.sizes()
 lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
 info = lv.info()

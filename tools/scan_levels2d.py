@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep / residual time of ONE 2-D Dirichlet level on the Gmsh-like cloud in sweep order, over tile sizes (same box).
-usage: scan_levels2d.py nside polydeg tile [tile ...]"""
+usage: scan_levels2d.py nside polydeg tile [tile ...]   -- env DSL="8,16": lanes per row of the one-wavefront dense layout"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,9 @@ ns, deg = int(sys.argv[1]), int(sys.argv[2])
 _host.set_option("device_setup", 1)
 pts = _host.quasi_uniform_square_cloud(ns)
 K = _host.stencil_size(deg)
-for t in [int(v) for v in sys.argv[3:]]:
+for t, dsl, mw in [(int(v), int(w), int(u)) for v in sys.argv[3:] for w in os.environ.get('DSL', '0').split(',') for u in os.environ.get('MAXW', '0').split(',')]:
+    _capi.set_option('dense_single_lanes', dsl)
+    _capi.set_option('max_workers', mw)
     g = _host.Grid.create_square(pts, deg, kind=_host.KIND_DIRICHLET, ordering=_host.ORDER_MC, tile_points=t)
     sz = g.sizes()
     lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
@@ -17,7 +19,7 @@ for t in [int(v) for v in sys.argv[3:]]:
     us = float(np.median(lv.time_sweeps(5, 7)[1:])) / 5 * 1e3
     usr = float(np.median(lv.time_residual(7)[1:])) * 1e3
     rows = info["sor_rows"]
-    print(json.dumps(dict(nside=ns, polydeg=deg, tile_opt=t, tiles=info["n_tiles"], waves=info["waves_per_tile"], lanes=info["lanes_per_row"],
+    print(json.dumps(dict(nside=ns, polydeg=deg, tile_opt=t, dsl=dsl, max_workers=mw, tiles=info["n_tiles"], waves=info["waves_per_tile"], lanes=info["lanes_per_row"],
                           groups_per_tile=round(info["n_groups"] / info["n_tiles"], 1), stream_B_per_row=round(info["stream_bytes"] / rows, 1),
                           us_per_sweep=round(us, 1), frac=round(rows * (12 * K + 28) / (us * 1e-6) / 8e12, 3), us_resid=round(usr, 1))), flush=True)
     del lv, g
