@@ -476,7 +476,10 @@ std::string build_plan(const PlanSpec &s, Plan *out)
             // 54^3 / 27^3 levels pay for the extra gather) -- g_dense_xtra_enabled: 1 = plans of at least 2e6 rows,
             // 2 = always (tests), 0 = never.
             const bool big = s.n_rows >= 2000000 || g_dense_xtra_enabled >= 2;
-            if (L == 16 && sd.dense_plen == 4 && maxent <= 3 * L + 1 && g_dense_xtra_enabled && big) { sd.dense_plen = 3; sd.dense_xtra = true; }
+            if (L == 16 && sd.dense_plen == 4 && maxent <= 3 * L + 1 && g_dense_xtra_enabled && big && s.dense_waves != 1) { sd.dense_plen = 3; sd.dense_xtra = true; }
+            // one wavefront per tile: kernels exist for 8 lanes x 3 ... 5 entries and 16 lanes x 3 entries (kernels_mw.hip)
+            if (s.dense_waves == 1 && !((L == 8 && sd.dense_plen <= 5) || (L == 16 && sd.dense_plen == 3)))
+                return "rows-too-long-for-dense";
         }
     }
 

@@ -64,10 +64,10 @@ def test_sweeps_residual_match_oracle(name, tile, L, sweep_mode):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 6), (48, 16, 3)])
+@pytest.mark.parametrize("tile,L,waves", [(64, 8, 4), (128, 16, 4), (96, 8, 2), (200, 8, 6), (48, 16, 3), (128, 8, -1), (160, 16, -1)])
 @pytest.mark.parametrize("mode", [0, 1, 4], ids=["per-phase", "auto", "single-launch"])
 def test_dense_multiwave_kernels_match_oracle(name, tile, L, waves, mode):
-    """Dense plans (mmg_level_desc.waves_per_tile > 1): workgroups of `waves` wavefronts per tile, one barrier
+    """Dense plans (mmg_level_desc.waves_per_tile > 1, or -1: ONE wavefront per tile): workgroups of `waves` wavefronts per tile, one barrier
     per round of mutually uncoupled rows (kernels_mw.hip) -- per-phase launches (tile_kernel_mw), the resident
     whole-sweep kernel ("auto" on these small levels: sweep_resident_mw) and the dependency-driven single launch
     (sweep_persistent_mw).  Same coupled-row order => the oracle's iterates to 1e-12; the three drivers agree bitwise."""
@@ -80,7 +80,11 @@ def test_dense_multiwave_kernels_match_oracle(name, tile, L, waves, mode):
     try:
         d = H.device_level(la, tile_size=tile, lanes_per_row=L, waves_per_tile=waves)
         rowlen = int(np.diff(la["rowptr"])[:-1 if la["neumann"] else None][la["bcflags"] == 0].max())
-        if rowlen - 2 <= 8 * L:
+        if waves == -1:   # one wavefront per tile: 8 lanes x <= 5 entries or 16 lanes x 3 entries, else the fallbacks below
+            fits = rowlen - 2 <= (40 if L == 8 else 48)
+        else:
+            fits = rowlen - 2 <= 8 * L
+        if fits:
             assert d.info()["waves_per_tile"] == waves
         else:   # the polyDeg-6 Neumann fixture: rows of ~190 entries take several row slots (4 / 6 wavefronts) or the packed stream
             assert d.info()["waves_per_tile"] in (1, 4, 6)

@@ -266,17 +266,19 @@ def test_sweep_ordered_level_dense_layout_with_one_wavefront_per_tile():
     o.sor_sweeps(2)
     ro = o.residual()
     nbytes = {}
-    for waves in (-1, 2):
-        e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=8, waves_per_tile=waves)
+    for waves, lanes in ((-1, 8), (2, 8), (-1, 16)):
+        e = H.EmuLevel(la, tile_ptr=g.tile_ptr(), lanes_per_row=lanes, waves_per_tile=waves)
         assert lib.emu_level_waves(e.h) == waves
         e.sweeps(2)
         assert H.rel_err(e.x, o.x) < 1e-12
         r, _nrm = e.residual()
         assert np.abs(r - ro).max() <= 1e-11 * max(1.0, np.abs(ro).max())
-        nbytes[waves] = lib.emu_level_stream_bytes(e.h)
+        nbytes[(waves, lanes)] = lib.emu_level_stream_bytes(e.h)
         # the sweep order shows as a long dependency chain: several times the ~20 colour classes of a coloured tile
         assert e.info()["n_groups"] / e.info()["n_tiles"] > 40 * (2 if waves == 2 else 1)
-    assert nbytes[-1] < 0.6 * nbytes[2]
+    assert nbytes[(-1, 8)] < 0.6 * nbytes[(2, 8)]
+    # K = 37 on 16 lanes x 3 entries: rounds of 4 rows are nearly full where rounds of 8 are not
+    assert nbytes[(-1, 16)] < 0.9 * nbytes[(-1, 8)]
 
 
 def test_dense_layout_extra_entry_plane_for_3d_stencils():
