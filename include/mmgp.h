@@ -109,7 +109,9 @@ int mmg_synchronize(void);
  * waits -- e.g. because kernels of the host application occupied the compute units -- and the
  * library restored x and repeated the sweeps (or the V-cycle body) with one launch per phase,
  * which always progresses.  The affected level keeps per-phase launches afterwards.  Callers see
- * no error: results are those of the reference's sequential sweep either way. */
+ * no error: results are those of the reference's sequential sweep either way.
+ * "plain_cycle_bodies" / "graph_launches" / "graph_captures": V-cycle bodies issued launch by launch, replayed as a
+ * HIP graph (mmg_set_option("vcycle_graph", 1)), and captures of such a graph. */
 int mmg_get_counter(const char *name, long long *value);
 /* "persistent_sweep": 0 one launch per phase; 1 (default) automatic -- single launch when a
  * sweep needs more than one residency round of tiles; 4 always single launch; 2 single launch
@@ -127,14 +129,18 @@ int mmg_get_counter(const char *name, long long *value);
  * "dense_single" (1/0): automatic layout only -- a dense level whose rounds are under 40 % full (levels relaxed in a sweep
  * order: ~4 uncoupled rows per dependency level) is rebuilt with ONE wavefront per tile (waves_per_tile = -1); 0 keeps
  * the multi-wavefront rounds (A/B).
+ * "dense_single_lanes" (0 automatic / 8 / 16): lanes per row of that one-wavefront layout -- automatic: 16 lanes x 3
+ * entries for K = 37 stencils (rounds of 4 rows are nearly full: 576 instead of 700 B per row), 8 lanes otherwise.
+ * "max_workers" (0: occupancy x compute units): cap on the workgroups of the dependency-driven sweep kernels (A/B aid).
  * "debug_fail_graph" (0/1): test hook -- the next instantiation of a captured V-cycle body "fails", the body is
  * issued with plain launches from then on (continuing from the flag epochs in front of the failed capture).
  * "waves_per_tile": layout of levels created afterwards whose descriptor leaves it 0 -- 0 automatic (by
  * level size and stencil width), 1 packed stream, 2 / 3 / 4 / 6 dense multi-wavefront layout.
  * "vcycle_graph" (default 0): 1: after one plain run the body of mmg_vcycle (everything after the residual
  * ratio: ~60 short launches) is captured into a HIP graph and replayed; re-captured when an option, omega /
- * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on MI355X (the
- * asynchronous launches never starve the stream), hence off by default. */
+ * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on a quiet host (the
+ * asynchronous launches never starve the stream), hence off by default; on a busy host the ~500 launches of a cycle
+ * with 60 coarse-grid sweeps did starve it (bench.py turns the graph on for its V-cycle and fractional-step legs). */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);

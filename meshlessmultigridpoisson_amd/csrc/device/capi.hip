@@ -879,8 +879,11 @@ int cycle_body(mmg_hierarchy *h)
     return MMG_OK;
 }
 
+long long g_plain_bodies = 0, g_graph_launches = 0, g_graph_captures = 0;  // mmg_get_counter
+
 int run_cycle_body_plain(mmg_hierarchy *h)
 {
+    if (!g_capturing) ++g_plain_bodies;
     for (mmg_level *l : h->lv) l->in_cycle = true;  // the hierarchy checks, not the levels
     const int rc = cycle_body(h);
     for (mmg_level *l : h->lv) l->in_cycle = false;
@@ -931,8 +934,10 @@ int run_cycle_body(mmg_hierarchy *h)
         }
         (void)hipGraphDestroy(graph);
         h->ggen = g_state_gen;
+        ++g_graph_captures;
     }
     HIPC(hipGraphLaunch(h->gexec, g_stream));
+    ++g_graph_launches;
     return MMG_OK;
 }
 
@@ -959,6 +964,22 @@ int settle_hierarchy(mmg_hierarchy *h)
     return repair_cycle(h);
 }
 
+// The cycle body with what its recovery needs: the fine-level x is saved in front of dependency-driven launches, and
+// h->unsettled says that the device error word has to be read before the result is relied on.
+int guarded_cycle_body(mmg_hierarchy *h)
+{
+    mmg_level *fine = h->lv.back();
+    bool guarded = false;
+    for (mmg_level *l : h->lv) guarded = guarded || use_resident_sweep(l) || use_single_launch(l) || (multi_rank(l) && !l->safe_mode);
+    if (guarded) {
+        if (h->x_backup.n != (size_t)fine->a_size) HIPC(h->x_backup.alloc((size_t)fine->a_size));
+        HIPC(hipMemcpyAsync(h->x_backup.p, fine->x.p, sizeof(double) * (size_t)fine->a_size, hipMemcpyDeviceToDevice, g_stream));
+    }
+    if (int rc = run_cycle_body(h)) return rc;
+    h->unsettled = guarded;
+    return MMG_OK;
+}
+
 // final: check the cycle body before returning (mmg_vcycle); otherwise the check rides on the residual
 // synchronisation of the next cycle (mmg_vcycles: one host round trip per cycle, as before)
 int vcycle_dev(mmg_hierarchy *h, double *resid_before, bool final = true)
@@ -980,14 +1001,7 @@ int vcycle_dev(mmg_hierarchy *h, double *resid_before, bool final = true)
         if ((rc = residual_ratio(fine, resid_before))) return rc;
     }
     h->unsettled = false;
-    bool guarded = false;
-    for (mmg_level *l : h->lv) guarded = guarded || use_resident_sweep(l) || use_single_launch(l) || (multi_rank(l) && !l->safe_mode);
-    if (guarded) {
-        if (h->x_backup.n != (size_t)fine->a_size) HIPC(h->x_backup.alloc((size_t)fine->a_size));
-        HIPC(hipMemcpyAsync(h->x_backup.p, fine->x.p, sizeof(double) * (size_t)fine->a_size, hipMemcpyDeviceToDevice, g_stream));
-    }
-    if ((rc = run_cycle_body(h))) return rc;
-    h->unsettled = guarded;
+    if ((rc = guarded_cycle_body(h))) return rc;
     return final ? settle_hierarchy(h) : MMG_OK;
 }
 
@@ -1063,6 +1077,9 @@ int mmg_get_counter(const char *name, long long *value)
 {
     if (!name || !value) return fail(MMG_ERR_INVALID, "null argument");
     if (std::strcmp(name, "sweep_fallbacks") == 0) { *value = g_sweep_fallbacks; return MMG_OK; }
+    if (std::strcmp(name, "plain_cycle_bodies") == 0) { *value = g_plain_bodies; return MMG_OK; }
+    if (std::strcmp(name, "graph_launches") == 0) { *value = g_graph_launches; return MMG_OK; }
+    if (std::strcmp(name, "graph_captures") == 0) { *value = g_graph_captures; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown counter ") + name);
 }
 
@@ -2357,18 +2374,32 @@ int mmg_fracstep_step(mmg_fracstep *fs, mmg_hierarchy *h, double dt, double mu, 
         return fail(MMG_ERR_INVALID, "fracstep_step: the hierarchy's finest level must be the fractional-step grid's level");
     int rc;
     mmg_level *fine = fs->p;
-    if ((rc = settle_hierarchy(h)) || (rc = settle(fine))) return rc;
+    if ((rc = settle_hierarchy(h))) return rc;
+    for (mmg_level *l : h->lv)
+        if ((rc = settle(l))) return rc;  // sweeps issued through the level API
     if ((rc = fs_apply_bound(fs))) return rc;
     if ((rc = mmg_fracstep_calc_hat(fs, dt, mu, rho))) return rc;
     if ((rc = mmg_fracstep_set_ppe_source(fs, dt, rho))) return rc;
     if ((rc = push_inhomog(fine))) return rc;
+    // while (mg.residual() >= tol) { mg.vCycle(); grid.bound_eval_neumann(); }  (FractionalStepSim.cpp:139-142).  The
+    // reference evaluates the fine residual twice per pass on the same state -- in the loop condition and again inside
+    // vCycle (multigrid.cpp:66) -- the second value only feeds residuals_; here ONE evaluation and ONE host round trip per
+    // pass serve both, and the check of the previous cycle body (device error word) rides on it.
     int nc = 0;
+    const bool single = h->frac_step && h->lv.size() == 1;   // FracStepMultigrid.cpp:64-67: a lone grid is just smoothed
     for (;;) {
         double ratio = 0.0;
-        if ((rc = residual_ratio(fine, &ratio))) return rc;  // mg.residual()
+        bool failed = false;
+        if ((rc = residual_ratio(fine, &ratio, &failed))) return rc;  // mg.residual()
+        if (failed && h->unsettled) {   // the previous body did not complete: repeat it (one launch per phase), then its boundary solve
+            h->unsettled = false;
+            if ((rc = repair_cycle(h)) || (rc = bound_eval(fine)) || (rc = residual_ratio(fine, &ratio))) return rc;
+        }
+        h->unsettled = false;
         if (!(ratio >= tol) || nc >= max_cycles) break;
-        double before = 0.0;
-        if ((rc = vcycle_dev(h, &before))) return rc;
+        if (single) rc = sweeps(fine, fine->iters);
+        else rc = guarded_cycle_body(h);
+        if (rc) return rc;
         if ((rc = bound_eval(fine))) return rc;
         ++nc;
     }

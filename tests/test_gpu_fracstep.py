@@ -83,9 +83,12 @@ def test_fracstep_3d_grid_ops_match_oracle(host):
     assert abs(g.fs_residual() - o.residual()) <= 1e-12 * o.residual()
 
 
+@pytest.mark.parametrize("graph", [0, 1], ids=["direct", "graph"])
 @pytest.mark.parametrize("dim,sides,deg", [(2, [15, 29], 3), (3, [7, 13], 2)])
-def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg):
-    """Two time steps of run_fracstep_param's loop, device-resident (mmg_fracstep_step through
+def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg, graph):
+    """(graph = 1: the cycle bodies of the pressure loop replayed as a HIP graph, mmg_set_option("vcycle_graph", 1), as
+    bench.py's fractional-step leg runs them; the graph is captured again when a time step changes what it froze.)
+    Two time steps of run_fracstep_param's loop, device-resident (mmg_fracstep_step through
     FractionalStepGrid::time_step), on a two-level FractionalStepMultigrid vs the same loop over oracle objects.
     The pressure loop is capped at 6 V-cycles per step (both sides reach the cap: 1e-10 is far below what six
     cycles give), so the comparison covers set_uv_bound, predictor, source, push_inhomog_to_rhs, six V-cycles
@@ -107,14 +110,22 @@ def test_device_resident_time_steps_match_oracle_loop(host, dim, sides, deg):
     _bt, _bp, bpts, _bv = g.boundaries()
     _xyz, flags = g.points()
     arrays = dict(bpts=bpts, bvals=[c[bpts].copy() for c in comps], coupling=g.coupling(), bcflags=flags)
-    for step in range(2):
-        r_dev, nc_dev = mg.step(max_cycles=6)
-        r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6)
-        assert nc_dev == nc_orc == 6, (step, nc_dev, nc_orc)
-        for got, want in zip(_vecs(g), comps):
-            assert H.rel_err(got, want) < 1e-9, step
-        assert H.rel_err(g.values()[:n], om.levels[-1].x[:n]) < 1e-9, step
-        assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)
+    from meshlessmultigridpoisson_amd import _capi
+    _capi.set_option("vcycle_graph", graph)
+    launches0 = _capi.get_counter("graph_launches")
+    try:
+        for step in range(2):
+            r_dev, nc_dev = mg.step(max_cycles=6)
+            r_orc, nc_orc = H.oracle_fracstep_time_step(om, ofs, arrays, g.dt, g.mu, g.rho, 1e-10, 6)
+            assert nc_dev == nc_orc == 6, (step, nc_dev, nc_orc)
+            for got, want in zip(_vecs(g), comps):
+                assert H.rel_err(got, want) < 1e-9, step
+            assert H.rel_err(g.values()[:n], om.levels[-1].x[:n]) < 1e-9, step
+            assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)
+    finally:
+        _capi.set_option("vcycle_graph", 0)
+    replayed = _capi.get_counter("graph_launches") - launches0
+    assert (replayed >= 8) if graph else (replayed == 0), replayed   # 12 cycle bodies, the first of a hierarchy runs plain
 
 
 def test_3d_time_step_converges_to_the_ppe_tolerance(host):
@@ -189,3 +200,37 @@ def test_distributed_time_step_single_rank_loopback(host, dim, sides, deg):
             assert abs(r_dev - r_orc) <= 1e-9 * abs(r_orc), (step, r_dev, r_orc)
     finally:
         _capi.comm_finalize()
+
+
+def test_pressure_loop_survives_a_failed_cycle_body(host):
+    """The pressure loop of mmg_fracstep_step checks a cycle body with the NEXT pass's residual (one host round trip per
+    pass).  A body whose dependency-driven launches run out of their bounded waits -- forced with
+    mmg_set_option("debug_spin_bound", 0) -- is repeated from the saved fine-level x with one launch per phase, its
+    boundary solve after it: the time step ends with the fields and the cycle count of an undisturbed run."""
+    from meshlessmultigridpoisson_amd import _capi
+
+    def run(disturb):
+        clouds = [host.box_cloud(n, 3, seed=12345 + i, edges=False) for i, n in enumerate([9, 17])]
+        mg = host.FracStepMultigrid(clouds, [2, 2], dim=3, dt=1e-3, mu=0.05, rho=1.0, ordering=host.ORDER_MC, tile_points=128)
+        g = mg.fs_grid()
+        g.prescribe_soln()
+        g.set_uv_bound()
+        before = _capi.get_counter("sweep_fallbacks")
+        if disturb:
+            _capi.set_option("persistent_sweep", 4)   # the ticket kernel on every level, whatever its size
+            _capi.set_option("debug_spin_bound", 0)
+        try:
+            r, nc = mg.step(max_cycles=5)
+        finally:
+            _capi.set_option("debug_spin_bound", -1)
+            _capi.set_option("persistent_sweep", 1)
+        return r, nc, [v.copy() for v in _vecs(g)], g.values().copy(), _capi.get_counter("sweep_fallbacks") - before
+
+    r0, nc0, vel0, p0, ev0 = run(False)
+    r1, nc1, vel1, p1, ev1 = run(True)
+    assert ev0 == 0 and ev1 >= 1
+    assert nc0 == nc1 == 5
+    assert abs(r0 - r1) <= 1e-12 * abs(r0)
+    for a, b in zip(vel0, vel1):
+        assert H.rel_err(b, a) < 1e-12
+    assert H.rel_err(p1, p0) < 1e-12
