@@ -95,6 +95,12 @@ __device__ __forceinline__ unsigned dense_slot(const DenseRegs<P> &g, int q)
     return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 struct NoGate {
     __device__ __forceinline__ bool operator()() const { return true; }
 };
@@ -235,20 +241,32 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
         double acc = row_sum<L>(acc0 + acc1);
         if (X) acc = fma(g.xval, xx, acc);  // (used by the row's first lane only)
         const uint32_t gid = g.info.x;
-        if (LONG) {
+        if constexpr (LONG && L == 16) {
             // Plan::dense_long: a row may continue in the row slots after its own (gid == kNoRow, self == kContSlot);
             // the head slot adds their sums, nearest first.  L = 16: four slots per wavefront.
-            constexpr int G = 64 / L;
+            // After row_sum every lane of a slot holds the slot's sum, and `cont` is uniform within a slot: the three
+            // later slots' sums and flags are read as SCALARS (v_readlane of the slots' first lanes, one ballot) instead
+            // of nine cross-lane shuffles through the LDS crossbar per round.
             const int slot = lane / L;
-            const int cont = (gid == kNoRow && (g.info.y & 0xffffu) == kContSlot) ? 1 : 0;
-            const double u1 = __shfl_down(acc, L, 64), u2 = __shfl_down(acc, 2 * L, 64), u3 = __shfl_down(acc, 3 * L, 64);
-            const int m1 = __shfl_down(cont, L, 64), m2 = __shfl_down(cont, 2 * L, 64), m3 = __shfl_down(cont, 3 * L, 64);
-            if (slot + 1 < G && m1) {
-                acc += u1;
-                if (slot + 2 < G && m2) {
-                    acc += u2;
-                    if (slot + 3 < G && m3) acc += u3;
+            const bool cont = gid == kNoRow && (g.info.y & 0xffffu) == kContSlot;
+            const unsigned long long cm = __ballot(cont);
+            const bool c1 = (cm >> L) & 1ull, c2 = (cm >> (2 * L)) & 1ull, c3 = (cm >> (3 * L)) & 1ull;
+            const double a1 = readlane_f64(acc, L), a2 = readlane_f64(acc, 2 * L), a3 = readlane_f64(acc, 3 * L);
+            if (slot == 0) {
+                if (c1) {
+                    acc += a1;
+                    if (c2) {
+                        acc += a2;
+                        if (c3) acc += a3;
+                    }
                 }
+            } else if (slot == 1) {
+                if (c2) {
+                    acc += a2;
+                    if (c3) acc += a3;
+                }
+            } else if (slot == 2) {
+                if (c3) acc += a3;
             }
         }
         if (sub == 0 && gid != kNoRow) {
