@@ -184,7 +184,7 @@ def algorithmic_bytes_per_vcycle(levels, k_interp, iters):
 
 
 def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
-    """Time `cycles` device-resident V-cycles of a host Multigrid (after 3 warm-up cycles)."""
+    """Time device-resident V-cycles of a host Multigrid: 3 warm-up cycles, then 3 batches of `cycles` cycles."""
     from meshlessmultigridpoisson_amd import _capi, _host
     # the cycle body replayed as a HIP graph: one launch per cycle from the host instead of ~60 -- the same kernels, the
     # same bits (tests/test_gpu_configs.py), the same time on a quiet host, but no starvation of the small-level
@@ -192,7 +192,13 @@ def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
     _capi.set_option("vcycle_graph", 1)
     try:
         mg.vcycles(3)
-        res, ms = mg.vcycles(cycles)
+        # three batches of `cycles` cycles back to back, the MEDIAN batch is reported (a single 10-cycle window right
+        # after the set-up kernels varied 16.6 ... 18.3 ms on the same build; every batch time is in the record)
+        batches = []
+        for _ in range(3):
+            res, ms = mg.vcycles(cycles)
+            batches.append(ms / cycles)
+        ms = float(np.median(batches)) * cycles
     finally:
         _capi.set_option("vcycle_graph", 0)
     levels = []
@@ -207,6 +213,7 @@ def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
     alg = algorithmic_bytes_per_vcycle(levels, k_i, iters)
     per = ms / cycles
     out = {"workload": what, "levels": sides, "polydeg": polys, "cycles": cycles, "ms_per_vcycle": per,
+           "ms_per_vcycle_batches": [float(v) for v in batches],
            "algorithmic_bytes_per_vcycle": alg, "achieved": alg / (per * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": alg / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "fine_Mpoints_per_s": sides[-1] ** dim / (per * 1e-3) / 1e6,
