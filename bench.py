@@ -195,8 +195,11 @@ def vcycle_leg(mg, what, dim, sides, polys, cycles, iters, oracle_cycles=0):
         # three batches of `cycles` cycles back to back, the MEDIAN batch is reported (a single 10-cycle window right
         # after the set-up kernels varied 16.6 ... 18.3 ms on the same build; every batch time is in the record)
         batches = []
+        res = None
         for _ in range(3):
-            res, ms = mg.vcycles(cycles)
+            rb, ms = mg.vcycles(cycles)
+            if res is None:
+                res = rb   # contraction: from the FIRST batch (the later ones may already sit on the round-off floor)
             batches.append(ms / cycles)
         ms = float(np.median(batches)) * cycles
     finally:
