@@ -88,8 +88,9 @@ __device__ __forceinline__ void issue_dense(const unsigned char *gp, int lane, D
     }
 }
 
+// LDS BYTE offset of entry q's column inside xs[] (plan.hpp: dense_slot_code = slot * 8)
 template <int P>
-__device__ __forceinline__ unsigned dense_slot(const DenseRegs<P> &g, int q)
+__device__ __forceinline__ unsigned dense_slot8(const DenseRegs<P> &g, int q)
 {
     const unsigned w = g.s[q >> 1];
     return (q & 1) ? (w >> 16) : (w & 0xffffu);
@@ -220,16 +221,19 @@ __device__ __forceinline__ void process_tile_mw(const TileArgs &a, const int til
     auto finish = [&](const DenseRegs<P> &g) {
         double xv[P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) xv[q] = xs[dense_slot<P>(g, q)];
+        for (int q = 0; q < P; ++q)   // address = stored 16 bits + the immediate offset of xs: no shift, no add
+            xv[q] = *reinterpret_cast<const double *>(reinterpret_cast<const unsigned char *>(xs) + dense_slot8<P>(g, q));
         double xx = 0.0;
         if (X) xx = xs[g.info.y >> 17];     // the extra entry's column (empty: the zero slot)
         // The row's own x and rhs are requested WITH the gathers, not after the reduction: they do not depend on the
         // row sum, and behind it they were one more LDS round trip on the critical path of every round (the
         // chain-bound levels pay rounds x this latency).  Rows of a round are distinct and mutually uncoupled and the
         // previous round's writes are complete (barrier), so the value read here is the one the update needs.
+        // (plans without multi-slot rows: every row slot -- the empty ones too, self = 0 -- names a slot of the own range;
+        // the continuation slots of multi-slot rows carry sentinels and need the range check)
         const uint32_t self_pre = g.info.y & 0xffffu;
-        const double x_self = xs[self_pre < n_slots ? self_pre : n_slots - 1];
-        const double b_self = bs[self_pre < n_own ? self_pre : 0];   // (n_own > 0 whenever the tile has rows)
+        const double x_self = xs[LONG ? (self_pre < n_slots ? self_pre : n_slots - 1) : self_pre];
+        const double b_self = bs[LONG ? (self_pre < n_own ? self_pre : 0) : self_pre];   // (n_own > 0 whenever the tile has rows)
         __builtin_amdgcn_sched_barrier(0);  // every gather in flight before the first FMA
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll

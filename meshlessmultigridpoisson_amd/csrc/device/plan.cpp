@@ -143,6 +143,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         return;
     }
     const uint16_t zero_slot = (uint16_t)(n_slots - 1);
+    const uint16_t zero_code = dense_slot_code(zero_slot);  // dense groups: slot * 8 (n_slots <= kMaxSlots < 8192)
     auto slot = [&](int32_t col) -> uint16_t {
         if (col >= lo && col < hi) return (uint16_t)(col - lo);
         return (uint16_t)slot_of[col];
@@ -282,7 +283,7 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                 }
                 for (int lane = 0; lane < 64; ++lane)
                     for (size_t q = 0; q < dense_slot_bytes(P) / 2; ++q)
-                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_slot, 2);
+                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_code, 2);
             }
             for (int k = 0; k < m; ++k) {
                 const int g = round_of[k] * NW + group_of[k];
@@ -301,7 +302,8 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     const int j = (int)(x / (size_t)per_slot), y = (int)(x % (size_t)per_slot);
                     const int q = y / L, lane = (i0 + j) * L + y % L;
                     std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
-                    std::memcpy(gp + dense_slot_off(L, P, q, lane), &e[x].slot, 2);
+                    const uint16_t code = dense_slot_code(e[x].slot);
+                    std::memcpy(gp + dense_slot_off(L, P, q, lane), &code, 2);
                 }
                 heads[(size_t)g]++;
             }
@@ -325,6 +327,8 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
         std::vector<std::vector<int32_t>> by_round(n_rounds);
         for (int k = 0; k < m; ++k) by_round[round_of[k]].push_back(k);
         const bool XT = s.dense_xtra;
+        for (int k = 0; k < m; ++k)
+            if (meta[k].self >= (uint32_t)n_own) { tb.err = "dense layout: a row without a slot in its tile's own range"; cleanup(); return; }
         const size_t GB = dense_group_bytes(L, P, XT);
         tb.blob.assign((size_t)n_rounds * NW * GB, 0);
         uint8_t *B = tb.blob.data();
@@ -334,14 +338,16 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                 uint8_t *gp = B + ((size_t)r * NW + w) * GB;
                 // everything empty first: no row, value 0, zero slot
                 for (int i = 0; i < G; ++i) {
-                    RowInfo ri{RowMeta{kNoRow, kNoSlot, (uint16_t)(XT ? (zero_slot << 1) : 0)}, 1.0};
+                    // (self = 0, a valid slot: the kernels read x[self] and b[self] of every row slot WITHOUT a range
+                    // check -- two compares and selects less per round; gid = kNoRow alone marks the empty slot)
+                    RowInfo ri{RowMeta{kNoRow, 0, (uint16_t)(XT ? (zero_slot << 1) : 0)}, 1.0};
                     std::memcpy(gp + (size_t)16 * i, &ri, 16);
                     const double one = 1.0;
                     std::memcpy(gp + dense_off_diag(L) + (size_t)8 * i, &one, 8);
                 }
                 for (int lane = 0; lane < 64; ++lane)
                     for (size_t q = 0; q < dense_slot_bytes(P) / 2; ++q)  // padding slots included
-                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_slot, 2);
+                        std::memcpy(gp + dense_off_slot(L, P) + (size_t)lane * dense_slot_bytes(P) + q * 2, &zero_code, 2);
                 int active = 0;
                 for (size_t idx = (size_t)w, i = 0; idx < rows.size(); idx += NW, ++i) {  // rows w, w+NW, ... of the round
                     const int k = rows[idx];
@@ -361,7 +367,8 @@ void build_tile(const Ctx &c, int t, std::vector<int32_t> &slot_of, TileBuild &t
                     for (size_t x = 0; x < n_lane; ++x) {
                         const int q = (int)(x / L), lane = (int)(i * L + x % L);
                         std::memcpy(gp + dense_val_off(L, P, q, lane), &e[x].val, 8);
-                        std::memcpy(gp + dense_slot_off(L, P, q, lane), &e[x].slot, 2);
+                        const uint16_t code = dense_slot_code(e[x].slot);
+                        std::memcpy(gp + dense_slot_off(L, P, q, lane), &code, 2);
                     }
                     ++active;
                 }

@@ -37,7 +37,7 @@
 //     rows that still has room), the wavefronts synchronise with one barrier per round;
 //   * layout of a group: RowInfo info[64/L] (16 B: RowMeta + 1/diag) | double diag[64/L] |
 //     double2 val[plen/2][64] (entries 2k, 2k+1 of a lane adjacent: one 16-byte load), for odd plen
-//     followed by double val_last[64] | uint16 slot[64][plen], padded to dense_slot_bytes(plen) per lane
+//     followed by double val_last[64] | uint16 slot8[64][plen] (= LDS slot * 8, dense_slot_code), padded to dense_slot_bytes(plen) per lane
 //     (8, 12 or 16 B: one load).  dense_val_off() / dense_slot_off() below are THE definition.
 //     Empty row slots: gid = 0xFFFFFFFF, values 0, slots = the tile's zero slot.
 //   * Plan::dense_long (16 lanes per row, 4 entries per lane): a row of more than 64 entries takes up to four
@@ -158,6 +158,11 @@ inline int dense_plen_class(int need)            // smallest instantiated shape 
         if (need <= p) return p;
     return 0;
 }
+// Dense groups store the LDS BYTE offset of an entry's column -- slot * 8 -- so that the gather address is the stored
+// 16 bits plus an immediate (one instruction less per entry in the latency-bound rounds; a tile has at most
+// kMaxSlots < 8192 slots).  (The extra entry's slot in RowMeta::flags >> 1 and RowMeta::self stay plain indices.)
+constexpr int kDenseSlotShift = 3;
+inline uint16_t dense_slot_code(uint32_t slot) { return (uint16_t)(slot << kDenseSlotShift); }
 inline size_t dense_slot_bytes(int plen) { return plen <= 4 ? 8 : (plen <= 6 ? 12 : 16); }  // per lane: one load
 inline size_t dense_off_diag(int L) { return (size_t)16 * (64 / L); }
 inline size_t dense_off_val(int L) { return (size_t)24 * (64 / L); }

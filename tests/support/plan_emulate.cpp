@@ -63,6 +63,7 @@ void run_tile_dense(const Plan &P, const TileDesc &td, int mode, std::vector<dou
                         uint16_t sl;
                         std::memcpy(&v, gp + dense_val_off(L, PL, q, (int)lane), 8);
                         std::memcpy(&sl, gp + dense_slot_off(L, PL, q, (int)lane), 2);
+                        sl = (uint16_t)(sl >> kDenseSlotShift);   // stored as the LDS byte offset
                         if (q & 1) a1 = std::fma(v, xs[sl], a1);
                         else a0 = std::fma(v, xs[sl], a0);
                     }
