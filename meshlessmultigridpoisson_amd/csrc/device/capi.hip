@@ -2057,10 +2057,10 @@ int rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud
     if (rc) return rc;
     if (n_eval == 0) return MMG_OK;
     RbfArgs a{};
-    const size_t lds = rbf_lds_bytes(stencil, pt, n_ops, &a.ld);
     int cus = 0, lds_cu = 0;
     if ((rc = mmg_device_props(&cus, &lds_cu))) return rc;
-    if (lds > (size_t)lds_cu) return fail(MMG_ERR_UNSUPPORTED, "rbf_weights: saddle system does not fit the LDS of one CU");
+    if (!rbf_supported(stencil, pt, n_ops, rbf_exp, lds_cu))
+        return fail(MMG_ERR_UNSUPPORTED, "rbf_weights: saddle system does not fit the LDS of one CU");
     DevBuf<double> d_cloud, d_eval, d_w;
     DevBuf<int> d_nbr, d_short;
     DevBuf<unsigned char> d_qf;
@@ -2078,7 +2078,6 @@ int rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud
     HIPC(d_nbr.alloc((size_t)std::min(n_eval, chunk) * stencil));
     HIPC(d_w.alloc((size_t)std::min(n_eval, chunk) * stencil * n_ops));
     if (flagged) HIPC(d_qf.alloc((size_t)std::min(n_eval, chunk)));
-    const int resident = std::max(1, cus * std::max(1, (int)((size_t)lds_cu / lds)));
     for (long long e0 = 0; e0 < n_eval; e0 += chunk) {
         const long long ne = std::min(chunk, n_eval - e0);
         HIPC(hipMemcpyAsync(d_eval.p, eval_xyz + 3 * e0, sizeof(double) * 3 * (size_t)ne, hipMemcpyHostToDevice, g_stream));
@@ -2116,7 +2115,7 @@ int rbf_stencils(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud
             HIPC(hipEventCreate(&ev1));
             HIPC(hipEventRecord(ev0, g_stream));
         }
-        HIPC(launch_rbf_weights(a, (int)std::min<long long>(ne, 2LL * resident), lds, g_stream));
+        HIPC(launch_rbf_weights(a, cus, lds_cu, g_stream));
         if (verbose) {
             HIPC(hipEventRecord(ev1, g_stream));
             HIPC(hipEventSynchronize(ev1));

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rbf_setup.hpp"
 
@@ -101,6 +102,53 @@ __device__ __forceinline__ double phs(double d, double m)
     if (m == 3.0) return d * d * d;
     if (m == 5.0) return d * d * d * d * d;
     return d > 0.0 ? pow(d, m) : 0.0;
+}
+
+// Entry i of the right-hand side of operator `op` (grid.cpp:312-331, :351-370, :389-413, :697-707): rows of the
+// stencil points (i < ss; xr, yr, zr = scaled coordinates of point i) and rows of the monomials (ax, bx, cx = exponents
+// of monomial i - ss); xe, ye, ze = scaled evaluation point.
+template <bool CUBIC = false>
+__device__ __forceinline__ double rhs_entry(int op, int i, int ss, int dim, double M, double xr, double yr, double zr, int ax,
+                                            int bx, int cx, double xe, double ye, double ze)
+{
+    double v = 0.0;
+    if (i < ss) {
+        if (op == RBF_OP_LAPLACE) {
+            double D = xe * xe - 2 * xe * xr + xr * xr + ye * ye - 2 * ye * yr + yr * yr;
+            double g2 = (2 * xe - 2 * xr) * (2 * xe - 2 * xr) + (2 * ye - 2 * yr) * (2 * ye - 2 * yr);
+            if (dim >= 3) {
+                D += ze * ze - 2 * ze * zr + zr * zr;
+                g2 += (2 * ze - 2 * zr) * (2 * ze - 2 * zr);
+            }
+            if (D > 0) {
+                if (CUBIC || M == 3.0) {  // pow(D, -1/2), pow(D, 1/2) without the generic pow
+                    const double sd = sqrt(D);
+                    v = g2 * (M / 2) * (M / 2 - 1) * (1.0 / sd) + dim * M * sd;
+                } else {
+                    v = g2 * (M / 2) * (M / 2 - 1) * pow(D, M / 2 - 2) + dim * M * pow(D, M / 2 - 1);
+                }
+            }
+        } else {
+            const double dx = xe - xr, dy = ye - yr, dz = ze - zr;
+            const double d = sqrt(dx * dx + dy * dy + dz * dz);
+            if (op == RBF_OP_INTERP) v = CUBIC ? d * d * d : phs(d, M);
+            else if (i > 0) {
+                const double delta = op == RBF_OP_DX ? dx : (op == RBF_OP_DY ? dy : dz);
+                v = M * ((CUBIC || M == 3.0) ? d : (d > 0.0 ? pow(d, M - 2) : 0.0)) * delta;
+            }
+        }
+    } else {
+        if (op == RBF_OP_INTERP) v = ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx);
+        else if (op == RBF_OP_DX) { if (ax >= 1) v = ax * ipow(xe, ax - 1) * ipow(ye, bx) * ipow(ze, cx); }
+        else if (op == RBF_OP_DY) { if (bx >= 1) v = bx * ipow(xe, ax) * ipow(ye, bx - 1) * ipow(ze, cx); }
+        else if (op == RBF_OP_DZ) { if (cx >= 1) v = cx * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 1); }
+        else {
+            if (ax >= 2) v += ax * (ax - 1) * ipow(xe, ax - 2) * ipow(ye, bx) * ipow(ze, cx);
+            if (bx >= 2) v += bx * (bx - 1) * ipow(xe, ax) * ipow(ye, bx - 2) * ipow(ze, cx);
+            if (cx >= 2) v += cx * (cx - 1) * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 2);
+        }
+    }
+    return v;
 }
 
 // One workgroup of NT threads, one stencil at a time.  LDS layout:
@@ -194,37 +242,10 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
                 const int i = lane;
                 double v = 0.0;
                 if (i < n) {
-                if (i < ss) {
-                    const double xr = sx[i], yr = sy[i], zr = sz[i];
-                    if (op == RBF_OP_LAPLACE) {
-                        double D = xe * xe - 2 * xe * xr + xr * xr + ye * ye - 2 * ye * yr + yr * yr;
-                        double g2 = (2 * xe - 2 * xr) * (2 * xe - 2 * xr) + (2 * ye - 2 * yr) * (2 * ye - 2 * yr);
-                        if (a.dim >= 3) {
-                            D += ze * ze - 2 * ze * zr + zr * zr;
-                            g2 += (2 * ze - 2 * zr) * (2 * ze - 2 * zr);
-                        }
-                        if (D > 0) v = g2 * (M / 2) * (M / 2 - 1) * pow(D, M / 2 - 2) + a.dim * M * pow(D, M / 2 - 1);
-                    } else {
-                        const double dx = xe - xr, dy = ye - yr, dz = ze - zr;
-                        const double d = sqrt(dx * dx + dy * dy + dz * dz);
-                        if (op == RBF_OP_INTERP) v = phs(d, M);
-                        else if (i > 0) {
-                            const double delta = op == RBF_OP_DX ? dx : (op == RBF_OP_DY ? dy : dz);
-                            v = M * (M == 3.0 ? d : (d > 0.0 ? pow(d, M - 2) : 0.0)) * delta;
-                        }
-                    }
-                } else {
-                    const int c = i - ss, ax = ea[c], bx = eb[c], cx = ec[c];
-                    if (op == RBF_OP_INTERP) v = ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx);
-                    else if (op == RBF_OP_DX) { if (ax >= 1) v = ax * ipow(xe, ax - 1) * ipow(ye, bx) * ipow(ze, cx); }
-                    else if (op == RBF_OP_DY) { if (bx >= 1) v = bx * ipow(xe, ax) * ipow(ye, bx - 1) * ipow(ze, cx); }
-                    else if (op == RBF_OP_DZ) { if (cx >= 1) v = cx * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 1); }
-                    else {
-                        if (ax >= 2) v += ax * (ax - 1) * ipow(xe, ax - 2) * ipow(ye, bx) * ipow(ze, cx);
-                        if (bx >= 2) v += bx * (bx - 1) * ipow(xe, ax) * ipow(ye, bx - 2) * ipow(ze, cx);
-                        if (cx >= 2) v += cx * (cx - 1) * ipow(xe, ax) * ipow(ye, bx) * ipow(ze, cx - 2);
-                    }
-                }
+                    const bool pnt = i < ss;
+                    const int c = pnt ? 0 : i - ss;
+                    v = rhs_entry(op, i, ss, a.dim, M, pnt ? sx[i] : 0.0, pnt ? sy[i] : 0.0, pnt ? sz[i] : 0.0, ea[c], eb[c], ec[c],
+                                  xe, ye, ze);
                 }
                 rreg[o] = v;
             }
@@ -361,6 +382,258 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
     }
 }
 
+
+// ---- one wavefront per stencil, the system in registers (systems of at most 72 x 72) --------------------
+// The 64 lanes form an 8 x 8 grid; lane (lr, lc) = (lane >> 3, lane & 7) keeps the RB x RB elements (a * 8 + lr,
+// b * 8 + lc) of the saddle system in registers, plus one more local column (b = RB): entry a * 8 + lr of the
+// right-hand side of operator lc.  Full pivoting WITHOUT moving data: a pivot (pr, pc) retires row pr and column pc
+// (bit masks of the lane's active local rows / columns), the rank-1 update runs over all RB x (RB + 1) elements with
+// the multipliers of retired rows and the pivot-row entries of retired columns set to zero, and carries the
+// right-hand sides with it (no L is stored: the pivot column is zeroed in the active rows).  Pivot row / column reach
+// the other lanes by one ds_bpermute per register along the lane grid's columns / rows; which local row / column is
+// meant is wave-uniform, so a scalar branch picks the registers.  The search for the next pivot is fused into the
+// update (largest |value|; among equals the lowest lane, then local row, then local column -- any largest element
+// is as stable as any other, Eigen's column-major tie rule is not reproduced here).  No LDS traffic and no barriers
+// inside the factorisation: per step ~ 2 RB^2 VALU instructions against 4 LDS accesses per element and three
+// workgroup barriers in the LDS kernel above.
+// Registers only: every index into the lane's block is a compile-time constant from the first optimisation pass on
+// (template recursion instead of loops -- an unrolled loop's constant indices appear too late, the optimiser has by
+// then merged the branches of a register choice into ONE load with a variable index, and the block lives in scratch).
+#define MMG_INL __attribute__((always_inline))
+template <int S, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (S < N) {
+        f(std::integral_constant<int, S>{});
+        static_for<S + 1, N>(f);
+    }
+}
+// f(I) for the one I in [S, N) equal to the wave-uniform i: a chain of scalar branches
+template <int S, int N, class F>
+__device__ __forceinline__ void static_switch(int i, F &&f)
+{
+    if constexpr (S < N) {
+        if (i == S) {
+            f(std::integral_constant<int, S>{});
+            // keeps the branches apart: merged, they would be one access with a variable register index (= scratch)
+            asm volatile("" ::: "memory");
+        } else {
+            static_switch<S + 1, N>(i, f);
+        }
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel(RbfArgs a)
+{
+    constexpr int CB = RB + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane0 = threadIdx.x;
+    const int ss = a.ss, pt = a.pt, n = ss + pt, d1 = a.poly_deg + 1;
+    // LDS of the wavefront: coordinates, their powers 0..poly_deg, 1 / pivot of every step, staged weights; step records
+    double *sx = reinterpret_cast<double *>(smem), *sy = sx + ss, *sz = sy + ss;
+    double *pwx = sz + ss, *pwy = pwx + ss * d1, *pwz = pwy + ss * d1;
+    double *srinv = pwz + ss * d1;
+    double *xs = srinv + n;
+    int *sinfo = reinterpret_cast<int *>(xs + (size_t)a.n_ops * ss);
+    unsigned char *ea = reinterpret_cast<unsigned char *>(sinfo + n);
+    unsigned char *eb = ea + pt;
+    unsigned char *ec = eb + pt;
+
+    if (lane0 == 0) {  // monomial exponents in the reference's enumeration order (grid.cpp:285-297)
+        int c = 0;
+        for (int p = 0; p <= a.poly_deg; ++p)
+            for (int q = 0; q <= p; ++q) {
+                if (a.dim < 3) {
+                    ea[c] = p - q; eb[c] = q; ec[c] = 0; ++c;
+                } else {
+                    for (int s = 0; s <= q; ++s) { ea[c] = p - q; eb[c] = q - s; ec[c] = s; ++c; }
+                }
+            }
+    }
+    __syncthreads();
+
+    for (long long e = blockIdx.x; e < a.n_eval; e += gridDim.x) {
+        // The lane id is opaque per stencil: nothing derived from it (the ~ 3 RB^2 LDS addresses and range tests of
+        // the assembly) is hoisted out of this loop, where it would occupy registers through the factorisation.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int lr = lane >> 3, lc = lane & 7;
+        const int my_op = lc < a.n_ops ? a.ops[lc] : -1;
+        const int src_row = lane & 0x38;  // + lane column of the pivot: the lane of this lane row that owns the pivot column
+        // ---- shifting_scaling ----
+        double lox = 1e300, hix = -1e300, loy = 1e300, hiy = -1e300, loz = 1e300, hiz = -1e300;
+        double cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
+        if (lane < ss) {
+            const long long id = a.nbr[e * ss + lane];
+            cx0 = a.cloud[3 * id]; cy0 = a.cloud[3 * id + 1]; cz0 = a.cloud[3 * id + 2];
+            lox = hix = cx0; loy = hiy = cy0; loz = hiz = cz0;
+        }
+        if (lane + 64 < ss) {
+            const long long id = a.nbr[e * ss + lane + 64];
+            cx1 = a.cloud[3 * id]; cy1 = a.cloud[3 * id + 1]; cz1 = a.cloud[3 * id + 2];
+            lox = fmin(lox, cx1); hix = fmax(hix, cx1);
+            loy = fmin(loy, cy1); hiy = fmax(hiy, cy1);
+            loz = fmin(loz, cz1); hiz = fmax(hiz, cz1);
+        }
+        lox = wmin(lox); hix = wmax(hix); loy = wmin(loy); hiy = wmax(hiy); loz = wmin(loz); hiz = wmax(hiz);
+        double scale = fmax(hix - lox, hiy - loy);
+        if (a.dim >= 3) scale = fmax(scale, hiz - loz);
+        else loz = 0.0;
+        for (int h = 0; h < 2; ++h) {
+            const int i = lane + 64 * h;
+            if (i < ss) {
+                const double x = ((h ? cx1 : cx0) - lox) / scale, y = ((h ? cy1 : cy0) - loy) / scale;
+                const double z = a.dim >= 3 ? ((h ? cz1 : cz0) - loz) / scale : 0.0;
+                sx[i] = x; sy[i] = y; sz[i] = z;
+                double px = 1.0, py = 1.0, pz = 1.0;
+                for (int p = 0; p < d1; ++p) {
+                    pwx[i * d1 + p] = px; pwy[i * d1 + p] = py; pwz[i * d1 + p] = pz;
+                    px *= x; py *= y; pz *= z;
+                }
+            }
+        }
+        for (int i = lane; i < a.n_ops * ss; i += 64) xs[i] = 0.0;
+        const double xe = (a.eval[3 * e] - lox) / scale, ye = (a.eval[3 * e + 1] - loy) / scale;
+        const double ze = a.dim >= 3 ? (a.eval[3 * e + 2] - loz) / scale : 0.0;
+        __syncthreads();
+
+        // ---- assemble [Phi P; P^T 0 | rhs] into the lane's registers ----
+        double v[RB][CB];
+        unsigned ract = 0, cact = 0;  // active local rows / columns of this lane
+        static_for<0, RB>([&](auto T) MMG_INL {
+            constexpr int t = decltype(T)::value;
+            if (t * 8 + lr < n) ract |= 1u << t;
+            if (t * 8 + lc < n) cact |= 1u << t;
+        });
+        double best = -1.0;
+        int bidx = 0x7fffffff;
+        static_for<0, RB>([&](auto AI) MMG_INL {
+            constexpr int ai = decltype(AI)::value;
+            const int i = ai * 8 + lr;
+            const bool ip = i < ss;
+            const double xi = ip ? sx[i] : 0.0, yi = ip ? sy[i] : 0.0, zi = ip ? sz[i] : 0.0;
+            const int ci = (!ip && i < n) ? i - ss : 0;
+            const int ea_i = ea[ci], eb_i = eb[ci], ec_i = ec[ci];
+            double m = 0.0;
+            static_for<0, RB>([&](auto BI) MMG_INL {
+                constexpr int bi = decltype(BI)::value;
+                const int j = bi * 8 + lc;
+                double val = 0.0;
+                if (ip && j < ss) {
+                    const double dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
+                    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+                    val = d * d * d;  // the kernel is launched for rbf_exp 3 only
+                } else if (ip && j < n) {
+                    const int c = j - ss;
+                    val = pwx[i * d1 + ea[c]] * pwy[i * d1 + eb[c]] * pwz[i * d1 + ec[c]];
+                } else if (j < ss && i < n) {
+                    val = pwx[j * d1 + ea_i] * pwy[j * d1 + eb_i] * pwz[j * d1 + ec_i];
+                }
+                v[ai][bi] = val;
+                m = fmax(m, fabs(val));
+                __builtin_amdgcn_sched_barrier(0);  // one element at a time: the block must not share its registers with 81 half-finished elements
+            });
+            v[ai][RB] = (my_op >= 0 && i < n) ? rhs_entry<true>(my_op, i, ss, a.dim, 3.0, xi, yi, zi, ea_i, eb_i, ec_i, xe, ye, ze) : 0.0;
+            if (((ract >> ai) & 1u) && m > best) { best = m; bidx = lane * 16 + ai; }
+        });
+
+        // ---- elimination with full pivoting, rows and columns stay where they are ----
+        int rank = n;
+        for (int k = 0; k < n; ++k) {
+            wave_argmax(best, bidx);
+            if (!(best > 0.0)) { rank = k; break; }
+            const int wl = __builtin_amdgcn_readfirstlane(bidx >> 4), as = __builtin_amdgcn_readfirstlane(bidx & 15);
+            // the winner's local row: the pivot row's entries in every lane of its lane row; which column won
+            double rowv[CB];
+            static_switch<0, RB>(as, [&](auto A) MMG_INL {
+                static_for<0, CB>([&](auto B) MMG_INL { rowv[decltype(B)::value] = v[decltype(A)::value][decltype(B)::value]; });
+            });
+            int bsel = 0;
+            static_for<0, RB>([&](auto B) MMG_INL {
+                constexpr int b = RB - 1 - decltype(B)::value;
+                if (fabs(rowv[b]) == best) bsel = b | (rowv[b] < 0.0 ? 16 : 0);
+            });
+            const int bw = __builtin_amdgcn_readlane(bsel, wl);
+            const int bs = bw & 15;
+            const double piv = (bw & 16) ? -best : best;
+            const double rinv = 1.0 / piv;
+            const int src_col = (wl & 0x38) | lc;  // the lane of this lane column that owns the pivot row
+            const int src = src_row | (wl & 7);
+            const bool own_col = lc == (wl & 7);
+            if (lr == (wl >> 3)) ract &= ~(1u << as);
+            if (own_col) cact &= ~(1u << bs);
+            double u[CB];
+            static_for<0, CB>([&](auto B) MMG_INL {
+                constexpr int b = decltype(B)::value;
+                u[b] = __shfl(rowv[b], src_col, 64);
+                if (b < RB && !((cact >> b) & 1u)) u[b] = 0.0;
+            });
+            // the pivot column: multipliers of the active rows; the column itself is zeroed there
+            double l[RB];
+            static_switch<0, RB>(bs, [&](auto B) MMG_INL {
+                constexpr int bb = decltype(B)::value;
+                static_for<0, RB>([&](auto T) MMG_INL {
+                    constexpr int t = decltype(T)::value;
+                    l[t] = v[t][bb];
+                    if (own_col && ((ract >> t) & 1u)) v[t][bb] = 0.0;
+                });
+            });
+            static_for<0, RB>([&](auto T) MMG_INL {
+                constexpr int t = decltype(T)::value;
+                l[t] = __shfl(l[t], src, 64) * rinv;
+                if (!((ract >> t) & 1u)) l[t] = 0.0;
+            });
+            if (lane == 0) { sinfo[k] = wl | (as << 8) | (bs << 12); srinv[k] = rinv; }
+            // rank-1 update of everything (retired rows / columns see zeros) + search of the next pivot
+            best = -1.0;
+            bidx = 0x7fffffff;
+            static_for<0, RB>([&](auto T) MMG_INL {
+                constexpr int t = decltype(T)::value;
+                double m = 0.0;
+                static_for<0, RB>([&](auto B) MMG_INL {
+                    constexpr int b = decltype(B)::value;
+                    v[t][b] = fma(-l[t], u[b], v[t][b]);
+                    m = fmax(m, fabs(v[t][b]));
+                });
+                v[t][RB] = fma(-l[t], u[RB], v[t][RB]);
+                if (((ract >> t) & 1u) && m > best) { best = m; bidx = lane * 16 + t; }
+            });
+        }
+        __syncthreads();  // step records visible
+
+        // ---- back substitution, last pivot first: lane column lc carries operator lc ----
+        for (int k = rank - 1; k >= 0; --k) {
+            const int info = __builtin_amdgcn_readfirstlane(sinfo[k]);
+            const int wl = info & 0xff, as = (info >> 8) & 15, bs = info >> 12;
+            const double rinv = srinv[k];
+            double t0 = 0.0;
+            static_switch<0, RB>(as, [&](auto A) MMG_INL { t0 = v[decltype(A)::value][RB]; });
+            const double x = __shfl(t0, (wl & 0x38) | lc, 64) * rinv;
+            const int pc = bs * 8 + (wl & 7);
+            if (lr == 0 && my_op >= 0 && pc < ss) xs[lc * ss + pc] = x;  // the polynomial multipliers are dropped
+            double cv[RB];
+            static_switch<0, RB>(bs, [&](auto B) MMG_INL {
+                static_for<0, RB>([&](auto T) MMG_INL { cv[decltype(T)::value] = v[decltype(T)::value][decltype(B)::value]; });
+            });
+            const int src = src_row | (wl & 7);
+            static_for<0, RB>([&](auto T) MMG_INL {
+                constexpr int t = decltype(T)::value;
+                v[t][RB] = fma(-__shfl(cv[t], src, 64), x, v[t][RB]);
+            });
+        }
+        __syncthreads();
+        for (int idx = lane; idx < a.n_ops * ss; idx += 64) {
+            const int o = idx / ss, c = idx - o * ss;
+            const int op = a.ops[o];
+            const double div = op == RBF_OP_LAPLACE ? scale * scale : (op == RBF_OP_INTERP ? 1.0 : scale);
+            a.w[((size_t)o * a.n_eval + e) * ss + c] = xs[idx] / div;
+        }
+        __syncthreads();
+    }
+}
+#undef MMG_INL
+
 }  // namespace
 
 size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out)
@@ -399,9 +672,62 @@ static hipError_t launch_nt(const RbfArgs &a, int blocks, size_t lds, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s)
+// the register kernel: one wavefront per workgroup
+static size_t rbf_wave_lds_bytes(const RbfArgs &a)
 {
+    const size_t ss = (size_t)a.ss, n = (size_t)a.ss + a.pt, d1 = (size_t)a.poly_deg + 1;
+    const size_t bytes = (3 * ss + 3 * ss * d1 + n + (size_t)a.n_ops * ss) * 8 + n * 4 + 3 * (size_t)a.pt;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+template <int RB>
+static hipError_t launch_wave(const RbfArgs &a, int cus, hipStream_t s)
+{
+    const size_t lds = rbf_wave_lds_bytes(a);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rbf_weights_wave_kernel<RB>, 64, lds) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    if (std::getenv("MMG_VERBOSE"))
+        std::fprintf(stderr, "[setup]   rbf_weights_wave_kernel<%d>: %zu B of LDS, %d wavefronts per CU\n", RB, lds, per_cu);
+    // a few stencils per resident wavefront: the grid-stride loop evens out the tail
+    const long long blocks = std::min<long long>(a.n_eval, 4LL * cus * per_cu);
+    hipLaunchKernelGGL(rbf_weights_wave_kernel<RB>, dim3((unsigned)blocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+// 0: no register kernel for this shape; else its RB
+static int rbf_wave_rb(int ss, int pt, int n_ops, double rbf_exp)
+{
+    static const int mode = []() {
+        const char *e = std::getenv("MMG_RBF_KERNEL");  // "lds": the LDS kernel for every shape (A/B, tests)
+        return (e && e[0] == 'l') ? 0 : 1;
+    }();
+    const int n = ss + pt;
+    if (!mode || n_ops > 8 || n > 72 || rbf_exp != 3.0) return 0;  // the register kernel: r^3, the reference's rbfExp
+    return n <= 40 ? 5 : (n <= 56 ? 7 : 9);
+}
+
+bool rbf_supported(int ss, int pt, int n_ops, double rbf_exp, int lds_cu)
+{
+    if (ss + pt > 256) return false;
+    if (rbf_wave_rb(ss, pt, n_ops, rbf_exp)) return true;
+    return rbf_lds_bytes(ss, pt, n_ops, nullptr) <= (size_t)lds_cu;
+}
+
+hipError_t launch_rbf_weights(RbfArgs a, int cus, int lds_cu, hipStream_t s)
+{
+    if (a.n_eval <= 0) return hipSuccess;
+    switch (rbf_wave_rb(a.ss, a.pt, a.n_ops, a.rbf_exp)) {
+    case 5: return launch_wave<5>(a, cus, s);
+    case 7: return launch_wave<7>(a, cus, s);
+    case 9: return launch_wave<9>(a, cus, s);
+    default: break;
+    }
     if (a.ss + a.pt > 256) return hipErrorInvalidValue;
+    const size_t lds = rbf_lds_bytes(a.ss, a.pt, a.n_ops, &a.ld);
+    if (lds > (size_t)lds_cu) return hipErrorInvalidValue;
+    const int resident = std::max(1, cus * std::max(1, (int)((size_t)lds_cu / lds)));
+    const int blocks = (int)std::min<long long>(a.n_eval, 2LL * resident);
     return rbf_threads(a.ss, a.pt) == 256 ? launch_nt<256>(a, blocks, lds, s) : launch_nt<64>(a, blocks, lds, s);
 }
 

@@ -20,9 +20,13 @@ struct RbfArgs {
     double rbf_exp;
 };
 
-// dynamic LDS of one workgroup; *ld_out = leading dimension of the column-major system
+// dynamic LDS of one workgroup of the LDS kernel; *ld_out = leading dimension of the column-major system
 size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out);
-hipError_t launch_rbf_weights(const RbfArgs &a, int blocks, size_t lds, hipStream_t s);
+// a kernel exists for this shape on a device with lds_cu bytes of LDS per CU: systems of at most 72 x 72 with the
+// cubic PHS (rbf_exp 3) are factorised in the registers of one wavefront, the others (up to 256 x 256) in LDS
+bool rbf_supported(int ss, int pt, int n_ops, double rbf_exp, int lds_cu);
+// picks the kernel, its grid and its LDS (a.ld is set here)
+hipError_t launch_rbf_weights(RbfArgs a, int cus, int lds_cu, hipStream_t s);
 
 }  // namespace mmg
 #endif
