@@ -69,6 +69,26 @@ __device__ __forceinline__ void wave_argmax(double &best, int &bidx)
     }
 }
 
+// wave-wide maximum, in every lane: four DPP steps inside the rows of 16 lanes, two shuffles across the rows
+template <int CTRL>
+__device__ __forceinline__ double max_dpp(double v)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffull), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return fmax(v, __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo)));
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = max_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = max_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = max_dpp<0x141>(v);  // row_half_mirror
+    v = max_dpp<0x140>(v);  // row_mirror
+    v = fmax(v, __shfl_xor(v, 16, 64));
+    v = fmax(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
 // block-wide max / min of six values at once (bounding box); red: 6 * (NT / 64) doubles of LDS
 template <int NT>
 __device__ __forceinline__ void block_minmax(double &lox, double &hix, double &loy, double &hiy, double &loz, double &hiz, double *red)
@@ -435,8 +455,8 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
     double *pwx = sz + ss, *pwy = pwx + ss * d1, *pwz = pwy + ss * d1;
     double *srinv = pwz + ss * d1;
     double *xs = srinv + n;
-    int *sinfo = reinterpret_cast<int *>(xs + (size_t)a.n_ops * ss);
-    unsigned char *ea = reinterpret_cast<unsigned char *>(sinfo + n);
+    int *rowcol = reinterpret_cast<int *>(xs + (size_t)a.n_ops * ss);  // row -> the unknown it solves for, -1: never a pivot row
+    unsigned char *ea = reinterpret_cast<unsigned char *>(rowcol + n);
     unsigned char *eb = ea + pt;
     unsigned char *ec = eb + pt;
 
@@ -494,20 +514,20 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
             }
         }
         for (int i = lane; i < a.n_ops * ss; i += 64) xs[i] = 0.0;
+        for (int i = lane; i < n; i += 64) rowcol[i] = -1;
         const double xe = (a.eval[3 * e] - lox) / scale, ye = (a.eval[3 * e + 1] - loy) / scale;
         const double ze = a.dim >= 3 ? (a.eval[3 * e + 2] - loz) / scale : 0.0;
         __syncthreads();
 
         // ---- assemble [Phi P; P^T 0 | rhs] into the lane's registers ----
         double v[RB][CB];
-        unsigned ract = 0, cact = 0;  // active local rows / columns of this lane
+        unsigned ract = 0;  // active local rows of this lane
         static_for<0, RB>([&](auto T) MMG_INL {
             constexpr int t = decltype(T)::value;
             if (t * 8 + lr < n) ract |= 1u << t;
-            if (t * 8 + lc < n) cact |= 1u << t;
         });
         double best = -1.0;
-        int bidx = 0x7fffffff;
+        int bidx = 0;
         static_for<0, RB>([&](auto AI) MMG_INL {
             constexpr int ai = decltype(AI)::value;
             const int i = ai * 8 + lr;
@@ -535,15 +555,21 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
                 __builtin_amdgcn_sched_barrier(0);  // one element at a time: the block must not share its registers with 81 half-finished elements
             });
             v[ai][RB] = (my_op >= 0 && i < n) ? rhs_entry<true>(my_op, i, ss, a.dim, 3.0, xi, yi, zi, ea_i, eb_i, ec_i, xe, ye, ze) : 0.0;
-            if (((ract >> ai) & 1u) && m > best) { best = m; bidx = lane * 16 + ai; }
+            if (((ract >> ai) & 1u) && m > best) { best = m; bidx = ai; }
         });
 
-        // ---- elimination with full pivoting, rows and columns stay where they are ----
+        // ---- Gauss-Jordan elimination with full pivoting, rows and columns stay where they are ----
+        // Every step already touches the lane's whole block (no data moves, so there is no shrinking trailing block
+        // to restrict it to): eliminating the pivot column from the RETIRED rows as well costs nothing extra and
+        // leaves a (permuted) diagonal system -- no back substitution, whose n steps would be one dependent chain of
+        // cross-lane round trips.  Retired columns are zero in every row, so the pivot row needs no column mask.
         int rank = n;
         for (int k = 0; k < n; ++k) {
-            wave_argmax(best, bidx);
-            if (!(best > 0.0)) { rank = k; break; }
-            const int wl = __builtin_amdgcn_readfirstlane(bidx >> 4), as = __builtin_amdgcn_readfirstlane(bidx & 15);
+            // largest candidate of the wavefront; among equals the lowest lane
+            const double mx = wave_max(best);
+            if (!(mx > 0.0)) { rank = k; break; }
+            const int wl = __builtin_ctzll(__ballot(best == mx));
+            const int as = __builtin_amdgcn_readlane(bidx, wl);
             // the winner's local row: the pivot row's entries in every lane of its lane row; which column won
             double rowv[CB];
             static_switch<0, RB>(as, [&](auto A) MMG_INL {
@@ -552,42 +578,46 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
             int bsel = 0;
             static_for<0, RB>([&](auto B) MMG_INL {
                 constexpr int b = RB - 1 - decltype(B)::value;
-                if (fabs(rowv[b]) == best) bsel = b | (rowv[b] < 0.0 ? 16 : 0);
+                if (fabs(rowv[b]) == mx) bsel = b | (rowv[b] < 0.0 ? 16 : 0);
             });
             const int bw = __builtin_amdgcn_readlane(bsel, wl);
             const int bs = bw & 15;
-            const double piv = (bw & 16) ? -best : best;
-            const double rinv = 1.0 / piv;
+            const double piv = (bw & 16) ? -mx : mx;
+            // 1 / pivot: v_rcp_f64 and two Newton steps (the quotient's last bit is not what limits these systems)
+            double rinv = __builtin_amdgcn_rcp(piv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
             const int src_col = (wl & 0x38) | lc;  // the lane of this lane column that owns the pivot row
-            const int src = src_row | (wl & 7);
-            const bool own_col = lc == (wl & 7);
-            if (lr == (wl >> 3)) ract &= ~(1u << as);
-            if (own_col) cact &= ~(1u << bs);
+            const int src = src_row | (wl & 7);    // the lane of this lane row that owns the pivot column
+            const bool own_col = lc == (wl & 7), own_row = lr == (wl >> 3);
+            if (own_row) ract &= ~(1u << as);
             double u[CB];
-            static_for<0, CB>([&](auto B) MMG_INL {
-                constexpr int b = decltype(B)::value;
-                u[b] = __shfl(rowv[b], src_col, 64);
-                if (b < RB && !((cact >> b) & 1u)) u[b] = 0.0;
-            });
-            // the pivot column: multipliers of the active rows; the column itself is zeroed there
+            static_for<0, CB>([&](auto B) MMG_INL { u[decltype(B)::value] = __shfl(rowv[decltype(B)::value], src_col, 64); });
+            // the pivot column: multipliers of ALL other rows; the column is zero from now on (the pivot itself is
+            // remembered as 1 / pivot), and the pivot row's entry of it does not take part in the update
             double l[RB];
             static_switch<0, RB>(bs, [&](auto B) MMG_INL {
                 constexpr int bb = decltype(B)::value;
                 static_for<0, RB>([&](auto T) MMG_INL {
                     constexpr int t = decltype(T)::value;
                     l[t] = v[t][bb];
-                    if (own_col && ((ract >> t) & 1u)) v[t][bb] = 0.0;
+                    if (own_col) v[t][bb] = 0.0;
                 });
+                if (own_col) u[bb] = 0.0;
             });
             static_for<0, RB>([&](auto T) MMG_INL {
                 constexpr int t = decltype(T)::value;
                 l[t] = __shfl(l[t], src, 64) * rinv;
-                if (!((ract >> t) & 1u)) l[t] = 0.0;
+                if (own_row && t == as) l[t] = 0.0;   // the pivot row stays
             });
-            if (lane == 0) { sinfo[k] = wl | (as << 8) | (bs << 12); srinv[k] = rinv; }
-            // rank-1 update of everything (retired rows / columns see zeros) + search of the next pivot
+            if (lane == wl) {  // row pr solves for unknown pc
+                const int pr = as * 8 + lr;
+                rowcol[pr] = bs * 8 + lc;
+                srinv[pr] = rinv;
+            }
+            // rank-1 update of the whole block + search of the next pivot among the active rows
             best = -1.0;
-            bidx = 0x7fffffff;
+            bidx = 0;
             static_for<0, RB>([&](auto T) MMG_INL {
                 constexpr int t = decltype(T)::value;
                 double m = 0.0;
@@ -597,31 +627,20 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
                     m = fmax(m, fabs(v[t][b]));
                 });
                 v[t][RB] = fma(-l[t], u[RB], v[t][RB]);
-                if (((ract >> t) & 1u) && m > best) { best = m; bidx = lane * 16 + t; }
+                if (((ract >> t) & 1u) && m > best) { best = m; bidx = t; }
             });
         }
-        __syncthreads();  // step records visible
-
-        // ---- back substitution, last pivot first: lane column lc carries operator lc ----
-        for (int k = rank - 1; k >= 0; --k) {
-            const int info = __builtin_amdgcn_readfirstlane(sinfo[k]);
-            const int wl = info & 0xff, as = (info >> 8) & 15, bs = info >> 12;
-            const double rinv = srinv[k];
-            double t0 = 0.0;
-            static_switch<0, RB>(as, [&](auto A) MMG_INL { t0 = v[decltype(A)::value][RB]; });
-            const double x = __shfl(t0, (wl & 0x38) | lc, 64) * rinv;
-            const int pc = bs * 8 + (wl & 7);
-            if (lr == 0 && my_op >= 0 && pc < ss) xs[lc * ss + pc] = x;  // the polynomial multipliers are dropped
-            double cv[RB];
-            static_switch<0, RB>(bs, [&](auto B) MMG_INL {
-                static_for<0, RB>([&](auto T) MMG_INL { cv[decltype(T)::value] = v[decltype(T)::value][decltype(B)::value]; });
-            });
-            const int src = src_row | (wl & 7);
-            static_for<0, RB>([&](auto T) MMG_INL {
-                constexpr int t = decltype(T)::value;
-                v[t][RB] = fma(-__shfl(cv[t], src, 64), x, v[t][RB]);
-            });
-        }
+        __syncthreads();  // rowcol / srinv visible
+        // ---- x[pc] = rhs[pr] / pivot: lane column lc carries operator lc; weights of the stencil points only ----
+        static_for<0, RB>([&](auto T) MMG_INL {
+            constexpr int t = decltype(T)::value;
+            const int i = t * 8 + lr;
+            if (my_op >= 0 && i < n) {
+                const int pc = rowcol[i];
+                if (pc >= 0 && pc < ss) xs[lc * ss + pc] = v[t][RB] * srinv[i];
+            }
+        });
+        (void)rank;
         __syncthreads();
         for (int idx = lane; idx < a.n_ops * ss; idx += 64) {
             const int o = idx / ss, c = idx - o * ss;
