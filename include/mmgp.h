@@ -140,7 +140,10 @@ int mmg_get_counter(const char *name, long long *value);
  * ratio: ~60 short launches) is captured into a HIP graph and replayed; re-captured when an option, omega /
  * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on a quiet host (the
  * asynchronous launches never starve the stream), hence off by default; on a busy host the ~500 launches of a cycle
- * with 60 coarse-grid sweeps did starve it (bench.py turns the graph on for its V-cycle and fractional-step legs). */
+ * with 60 coarse-grid sweeps did starve it (bench.py turns the graph on for its V-cycle and fractional-step legs).
+ * "rbf_kernel" (0 automatic / 1): mmg_rbf_weights / mmg_rbf_stencils -- 0: saddle systems of at most 72 x 72 with
+ * rbf_exp 3 are factorised in the registers of one wavefront, the others in LDS; 1: the LDS kernel for every shape
+ * (tests compare the two; different pivot ties, same solution to the conditioning of the system). */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);
@@ -296,7 +299,10 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny);
  *   nbr       [n_eval][stencil]  neighbour ids into cloud_xyz, nearest first (kNearestNeighbors)
  *   ops       [n_ops]       0 laplace, 1 d/dx, 2 d/dy, 3 d/dz, 4 interpolation (<= 4 per call,
  *                           solved against ONE factorisation)
- *   weights   [n_ops][n_eval][stencil]  out: the first `stencil` solution entries */
+ *   weights   [n_ops][n_eval][stencil]  out: the first `stencil` solution entries
+ * Full pivoting as fullPivLu, i.e. the same pivot VALUES; among equal candidates the register kernel (systems up
+ * to 72 x 72) takes another one than Eigen's column-major scan, and it eliminates Gauss-Jordan fashion: weights
+ * agree with the reference's to the conditioning of the scaled saddle system (tests: 1e-6 of the row's largest). */
 int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
                     long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,
                     double *weights);

@@ -28,6 +28,7 @@
 #include "rbf_setup.hpp"
 
 namespace mmg {
+int g_rbf_lds_only = 0;  // mmg_set_option("rbf_kernel", 1): the LDS kernel for every shape (tests compare the two)
 namespace {
 
 __device__ __forceinline__ double wmax(double v)
@@ -718,11 +719,11 @@ static hipError_t launch_wave(const RbfArgs &a, int cus, hipStream_t s)
 static int rbf_wave_rb(int ss, int pt, int n_ops, double rbf_exp)
 {
     static const int mode = []() {
-        const char *e = std::getenv("MMG_RBF_KERNEL");  // "lds": the LDS kernel for every shape (A/B, tests)
+        const char *e = std::getenv("MMG_RBF_KERNEL");  // "lds": the LDS kernel for every shape (A/B)
         return (e && e[0] == 'l') ? 0 : 1;
     }();
     const int n = ss + pt;
-    if (!mode || n_ops > 8 || n > 72 || rbf_exp != 3.0) return 0;  // the register kernel: r^3, the reference's rbfExp
+    if (!mode || g_rbf_lds_only || n_ops > 8 || n > 72 || rbf_exp != 3.0) return 0;  // the register kernel: r^3, the reference's rbfExp
     return n <= 40 ? 5 : (n <= 56 ? 7 : 9);
 }
 

@@ -20,6 +20,8 @@ struct RbfArgs {
     double rbf_exp;
 };
 
+extern int g_rbf_lds_only;  // option "rbf_kernel": 0 = automatic (register kernel where it applies), 1 = LDS kernel only
+
 // dynamic LDS of one workgroup of the LDS kernel; *ld_out = leading dimension of the column-major system
 size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out);
 // a kernel exists for this shape on a device with lds_cu bytes of LDS per CU: systems of at most 72 x 72 with the

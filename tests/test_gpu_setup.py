@@ -373,3 +373,73 @@ def test_fracstep_operator_cache_follows_polydeg_changes(host):
     finally:
         host.set_option("device_setup", -1)
     assert (out[0], out[1]) == (host.stencil_size(3), host.stencil_size(4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg,ss,ops", [(3, 3, 50, [0]), (3, 3, 50, [1, 2, 3, 0]), (2, 3, 25, [0, 1, 2]), (2, 4, 37, [4]),
+                                            (2, 5, 51, [0]), (3, 2, 30, [0, 4]), (2, 6, 70, [0])])
+def test_rbf_register_kernel_matches_lds_kernel_and_reproduces_polynomials(host, dim, deg, ss, ops):
+    """The two kernels behind mmg_rbf_weights (rbf_setup.hip): systems of at most 72 x 72 are factorised in the
+    registers of one wavefront (Gauss-Jordan, full pivoting without data movement), larger ones in LDS (LU with full
+    pivoting as the reference's fullPivLu, grid.cpp:304-424, :687-712).  Same stencils through both (option
+    "rbf_kernel"): weights equal to 1e-6 of the row's largest (conditioning of the scaled saddle systems; observed
+    2e-7), and -- independent of either -- every row reproduces the operator on all monomials up to polyDeg, which
+    is what the polynomial block of the saddle system enforces (1e-8 relative to the row's magnitude).  (2, 5, 51) is
+    the largest system of the register kernel (72 x 72), (2, 6, 70) is 98 x 98: LDS kernel on both sides."""
+    from meshlessmultigridpoisson_amd import _capi
+    rng = np.random.default_rng(11)
+    side = 40 if dim == 2 else 14
+    ax = [np.arange(side) / (side - 1.0)] * dim
+    pts = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, dim)
+    pts = pts + (rng.random(pts.shape) - 0.5) * 0.4 / (side - 1.0)
+    xyz = np.zeros((len(pts), 3))
+    xyz[:, :dim] = pts
+    ev = xyz[rng.choice(len(xyz), 1500, replace=False)] + 0.2 / (side - 1.0) * (rng.random((1500, 3)) - 0.5) * (np.arange(3) < dim)
+    nbr = _capi.knn(dim, xyz, ev, ss)
+    try:
+        _capi.set_option("rbf_kernel", 1)
+        w_lds = _capi.rbf_weights(dim, deg, 3.0, xyz, ev, nbr, ops)
+    finally:
+        _capi.set_option("rbf_kernel", 0)
+    w = _capi.rbf_weights(dim, deg, 3.0, xyz, ev, nbr, ops)
+    assert np.isfinite(w).all()
+    scale = np.abs(w_lds).max(axis=2, keepdims=True)
+    assert (np.abs(w - w_lds) / scale).max() <= 1e-6
+    # polynomial reproduction in coordinates centred on the evaluation point (so the check does not cancel)
+    rel = xyz[nbr] - ev[:, None, :]                                   # [n_eval][ss][3]
+    h = np.abs(rel).max(axis=(1, 2))                                   # stencil radius
+    for o, op in enumerate(ops):
+        for (a, b, c) in _monomials(dim, deg):
+            p = rel[..., 0] ** a * rel[..., 1] ** b * rel[..., 2] ** c
+            got = (w[o] * p).sum(axis=1)
+            if op == 4:
+                want = 1.0 if a + b + c == 0 else 0.0
+            elif op == 0:
+                want = 2.0 if sorted((a, b, c)) == [0, 0, 2] else 0.0
+            else:
+                e = [0, 0, 0]
+                e[op - 1] = 1
+                want = 1.0 if [a, b, c] == e else 0.0
+            mag = (np.abs(w[o]) * np.abs(p)).sum(axis=1) + h ** (a + b + c) * 1e-300
+            assert (np.abs(got - want) / np.maximum(mag, abs(want))).max() <= 1e-8, (op, a, b, c)
+
+
+@pytest.mark.gpu
+def test_rbf_register_kernel_on_coincident_stencil_points(host):
+    """Two coincident stencil points make the saddle system singular (two equal rows and columns): elimination stops
+    at the rank (no positive pivot candidate left), the unknowns never pivoted on stay zero -- finite weights from both
+    kernels, no fault; the solution is not unique, so nothing more is compared."""
+    from meshlessmultigridpoisson_amd import _capi
+    rng = np.random.default_rng(5)
+    xyz = np.zeros((400, 3))
+    xyz[:, :2] = rng.random((400, 2))
+    xyz[1] = xyz[0]
+    ev = xyz[:50].copy()
+    nbr = np.tile(np.arange(25, dtype=np.int32), (50, 1))              # every stencil holds the coincident pair
+    for mode in (0, 1):
+        try:
+            _capi.set_option("rbf_kernel", mode)
+            w = _capi.rbf_weights(2, 3, 3.0, xyz, ev, nbr, [0, 4])
+        finally:
+            _capi.set_option("rbf_kernel", 0)
+        assert np.isfinite(w).all()
