@@ -1054,7 +1054,7 @@ int mmg_set_option(const char *name, int value)
     if (std::strcmp(name, "debug_fail_graph") == 0) { g_debug_fail_graph = value; return MMG_OK; }
     if (std::strcmp(name, "dense_single") == 0) { g_dense_single = value; return MMG_OK; }
     if (std::strcmp(name, "dense_xtra") == 0) { mmg::g_dense_xtra_enabled = value; return MMG_OK; }
-    if (std::strcmp(name, "rbf_kernel") == 0) { mmg::g_rbf_lds_only = value == 1; return MMG_OK; }
+    if (std::strcmp(name, "rbf_kernel") == 0) { mmg::g_rbf_lds_only = value == 1; mmg::g_rbf_one_wave = value == 2; return MMG_OK; }
     return fail(MMG_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -29,6 +29,7 @@
 
 namespace mmg {
 int g_rbf_lds_only = 0;  // mmg_set_option("rbf_kernel", 1): the LDS kernel for every shape (tests compare the two)
+int g_rbf_one_wave = 0;  // mmg_set_option("rbf_kernel", 2): 57 <= n <= 72 in one wavefront instead of two (A/B, tests)
 namespace {
 
 __device__ __forceinline__ double wmax(double v)
@@ -652,6 +653,230 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
         __syncthreads();
     }
 }
+
+// ---- two wavefronts per stencil (57 <= n <= 72: the 70 x 70 systems of the 3-D degree-3 stencils) ----
+// The RB = 9 block of the kernel above fills the register file of a SIMD with ONE wavefront.  Here a workgroup of two
+// wavefronts shares the stencil: a 16 x 8 lane grid, wavefront w owns the lane rows 8w .. 8w + 7, lane (r, c) the
+// RBR x RBC elements (16a + r, 8b + c) and entry 16a + r of the right-hand side of operator c -- 5 x 10 instead of
+// 9 x 10 values per lane, two wavefronts per SIMD.  The pivot COLUMN stays inside each wavefront (every wavefront holds
+// all columns of its rows: ds_bpermute along the lane rows as above); the pivot ROW lives in one wavefront and
+// reaches the other through LDS, as does the choice between the two wavefronts' pivot candidates: two workgroup
+// barriers per step, nothing else crosses.
+template <int RBR, int RBC>
+__global__ __launch_bounds__(128, 2) void rbf_weights_wave2_kernel(RbfArgs a)
+{
+    constexpr int CB = RBC + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid0 = threadIdx.x;
+    const int ss = a.ss, pt = a.pt, n = ss + pt, d1 = a.poly_deg + 1;
+    double *sx = reinterpret_cast<double *>(smem), *sy = sx + ss, *sz = sy + ss;
+    double *pwx = sz + ss, *pwy = pwx + ss * d1, *pwz = pwy + ss * d1;
+    double *srinv = pwz + ss * d1;
+    double *xs = srinv + n;
+    double *ubuf = xs + (size_t)a.n_ops * ss;   // pivot row: 8 RBC entries + 8 right-hand sides
+    double *red_best = ubuf + 8 * CB;           // [2] the wavefronts' candidates
+    int *red_idx = reinterpret_cast<int *>(red_best + 2);  // [2] lane << 4 | local row; [2]: local column | sign << 4
+    int *rowcol = red_idx + 4;
+    unsigned char *ea = reinterpret_cast<unsigned char *>(rowcol + n);
+    unsigned char *eb = ea + pt;
+    unsigned char *ec = eb + pt;
+
+    if (tid0 == 0) {  // monomial exponents in the reference's enumeration order (grid.cpp:285-297)
+        int c = 0;
+        for (int p = 0; p <= a.poly_deg; ++p)
+            for (int q = 0; q <= p; ++q) {
+                if (a.dim < 3) {
+                    ea[c] = p - q; eb[c] = q; ec[c] = 0; ++c;
+                } else {
+                    for (int s = 0; s <= q; ++s) { ea[c] = p - q; eb[c] = q - s; ec[c] = s; ++c; }
+                }
+            }
+    }
+    __syncthreads();
+
+    for (long long e = blockIdx.x; e < a.n_eval; e += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));  // opaque per stencil (see the one-wavefront kernel)
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63, lc = lane & 7, lrw = lane >> 3, r = w * 8 + lrw;
+        const int my_op = lc < a.n_ops ? a.ops[lc] : -1;
+        const int src_row = lane & 0x38;
+
+        // ---- shifting_scaling (both wavefronts reduce the whole stencil; wavefront 0 writes it) ----
+        double lox = 1e300, hix = -1e300, loy = 1e300, hiy = -1e300, loz = 1e300, hiz = -1e300;
+        double cx0 = 0, cy0 = 0, cz0 = 0, cx1 = 0, cy1 = 0, cz1 = 0;
+        if (lane < ss) {
+            const long long id = a.nbr[e * ss + lane];
+            cx0 = a.cloud[3 * id]; cy0 = a.cloud[3 * id + 1]; cz0 = a.cloud[3 * id + 2];
+            lox = hix = cx0; loy = hiy = cy0; loz = hiz = cz0;
+        }
+        if (lane + 64 < ss) {
+            const long long id = a.nbr[e * ss + lane + 64];
+            cx1 = a.cloud[3 * id]; cy1 = a.cloud[3 * id + 1]; cz1 = a.cloud[3 * id + 2];
+            lox = fmin(lox, cx1); hix = fmax(hix, cx1);
+            loy = fmin(loy, cy1); hiy = fmax(hiy, cy1);
+            loz = fmin(loz, cz1); hiz = fmax(hiz, cz1);
+        }
+        lox = wmin(lox); hix = wmax(hix); loy = wmin(loy); hiy = wmax(hiy); loz = wmin(loz); hiz = wmax(hiz);
+        double scale = fmax(hix - lox, hiy - loy);
+        if (a.dim >= 3) scale = fmax(scale, hiz - loz);
+        else loz = 0.0;
+        if (w == 0) {
+            for (int h = 0; h < 2; ++h) {
+                const int i = lane + 64 * h;
+                if (i < ss) {
+                    const double x = ((h ? cx1 : cx0) - lox) / scale, y = ((h ? cy1 : cy0) - loy) / scale;
+                    const double z = a.dim >= 3 ? ((h ? cz1 : cz0) - loz) / scale : 0.0;
+                    sx[i] = x; sy[i] = y; sz[i] = z;
+                    double px = 1.0, py = 1.0, pz = 1.0;
+                    for (int p = 0; p < d1; ++p) {
+                        pwx[i * d1 + p] = px; pwy[i * d1 + p] = py; pwz[i * d1 + p] = pz;
+                        px *= x; py *= y; pz *= z;
+                    }
+                }
+            }
+        }
+        for (int i = tid; i < a.n_ops * ss; i += 128) xs[i] = 0.0;
+        for (int i = tid; i < n; i += 128) rowcol[i] = -1;
+        const double xe = (a.eval[3 * e] - lox) / scale, ye = (a.eval[3 * e + 1] - loy) / scale;
+        const double ze = a.dim >= 3 ? (a.eval[3 * e + 2] - loz) / scale : 0.0;
+        __syncthreads();
+
+        // ---- assemble [Phi P; P^T 0 | rhs] into the lane's registers ----
+        double v[RBR][CB];
+        unsigned ract = 0;
+        static_for<0, RBR>([&](auto T) MMG_INL {
+            constexpr int t = decltype(T)::value;
+            if (t * 16 + r < n) ract |= 1u << t;
+        });
+        double best = -1.0;
+        int bidx = 0;
+        static_for<0, RBR>([&](auto AI) MMG_INL {
+            constexpr int ai = decltype(AI)::value;
+            const int i = ai * 16 + r;
+            const bool ip = i < ss;
+            const double xi = ip ? sx[i] : 0.0, yi = ip ? sy[i] : 0.0, zi = ip ? sz[i] : 0.0;
+            const int ci = (!ip && i < n) ? i - ss : 0;
+            const int ea_i = ea[ci], eb_i = eb[ci], ec_i = ec[ci];
+            double m = 0.0;
+            static_for<0, RBC>([&](auto BI) MMG_INL {
+                constexpr int bi = decltype(BI)::value;
+                const int j = bi * 8 + lc;
+                double val = 0.0;
+                if (ip && j < ss) {
+                    const double dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
+                    const double d = sqrt(dx * dx + dy * dy + dz * dz);
+                    val = d * d * d;
+                } else if (ip && j < n) {
+                    const int c = j - ss;
+                    val = pwx[i * d1 + ea[c]] * pwy[i * d1 + eb[c]] * pwz[i * d1 + ec[c]];
+                } else if (j < ss && i < n) {
+                    val = pwx[j * d1 + ea_i] * pwy[j * d1 + eb_i] * pwz[j * d1 + ec_i];
+                }
+                v[ai][bi] = val;
+                m = fmax(m, fabs(val));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            v[ai][RBC] = (my_op >= 0 && i < n) ? rhs_entry<true>(my_op, i, ss, a.dim, 3.0, xi, yi, zi, ea_i, eb_i, ec_i, xe, ye, ze) : 0.0;
+            if (((ract >> ai) & 1u) && m > best) { best = m; bidx = ai; }
+        });
+
+        // ---- Gauss-Jordan elimination with full pivoting, as above; two barriers per step ----
+        for (int k = 0; k < n; ++k) {
+            {   // this wavefront's candidate
+                const double mxw = wave_max(best);
+                const int wlw = __builtin_ctzll(__ballot(best == mxw));
+                const int asw = __builtin_amdgcn_readlane(bidx, wlw);
+                if (lane == 0) { red_best[w] = mxw; red_idx[w] = (wlw << 4) | asw; }
+            }
+            __syncthreads();
+            const double b0 = red_best[0], b1 = red_best[1];
+            const int ww = __builtin_amdgcn_readfirstlane(b1 > b0 ? 1 : 0);  // among equals wavefront 0
+            const double mx = ww ? b1 : b0;
+            if (!(mx > 0.0)) break;  // both wavefronts read the same pair
+            const int wi = __builtin_amdgcn_readfirstlane(red_idx[ww]);
+            const int wl = wi >> 4, as = wi & 15;
+            if (w == ww) {
+                // the winner's local row: to LDS from the lanes of its lane row; which column won
+                double rowv[CB];
+                static_switch<0, RBR>(as, [&](auto A) MMG_INL {
+                    static_for<0, CB>([&](auto B) MMG_INL { rowv[decltype(B)::value] = v[decltype(A)::value][decltype(B)::value]; });
+                });
+                int bsel = 0;
+                static_for<0, RBC>([&](auto B) MMG_INL {
+                    constexpr int b = RBC - 1 - decltype(B)::value;
+                    if (fabs(rowv[b]) == mx) bsel = b | (rowv[b] < 0.0 ? 16 : 0);
+                });
+                if (lrw == (wl >> 3)) {
+                    static_for<0, CB>([&](auto B) MMG_INL { ubuf[decltype(B)::value * 8 + lc] = rowv[decltype(B)::value]; });
+                    ract &= ~(1u << as);
+                }
+                if (lane == wl) red_idx[2] = bsel;
+            }
+            __syncthreads();
+            const int bw = __builtin_amdgcn_readfirstlane(red_idx[2]);
+            const int bs = bw & 15;
+            const double piv = (bw & 16) ? -mx : mx;
+            double rinv = __builtin_amdgcn_rcp(piv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+            rinv = fma(fma(-piv, rinv, 1.0), rinv, rinv);
+            const bool own_col = lc == (wl & 7), own_row = (w == ww) && lrw == (wl >> 3);
+            double u[CB];
+            static_for<0, CB>([&](auto B) MMG_INL { u[decltype(B)::value] = ubuf[decltype(B)::value * 8 + lc]; });
+            double l[RBR];
+            static_switch<0, RBC>(bs, [&](auto B) MMG_INL {
+                constexpr int bb = decltype(B)::value;
+                static_for<0, RBR>([&](auto T) MMG_INL {
+                    constexpr int t = decltype(T)::value;
+                    l[t] = v[t][bb];
+                    if (own_col) v[t][bb] = 0.0;
+                });
+                if (own_col) u[bb] = 0.0;
+            });
+            const int src = src_row | (wl & 7);
+            static_for<0, RBR>([&](auto T) MMG_INL {
+                constexpr int t = decltype(T)::value;
+                l[t] = __shfl(l[t], src, 64) * rinv;
+                if (own_row && t == as) l[t] = 0.0;
+            });
+            if (own_row && own_col) {  // row pr solves for unknown pc
+                const int pr = as * 16 + r;
+                rowcol[pr] = bs * 8 + lc;
+                srinv[pr] = rinv;
+            }
+            best = -1.0;
+            bidx = 0;
+            static_for<0, RBR>([&](auto T) MMG_INL {
+                constexpr int t = decltype(T)::value;
+                double m = 0.0;
+                static_for<0, RBC>([&](auto B) MMG_INL {
+                    constexpr int b = decltype(B)::value;
+                    v[t][b] = fma(-l[t], u[b], v[t][b]);
+                    m = fmax(m, fabs(v[t][b]));
+                });
+                v[t][RBC] = fma(-l[t], u[RBC], v[t][RBC]);
+                if (((ract >> t) & 1u) && m > best) { best = m; bidx = t; }
+            });
+        }
+        __syncthreads();
+        static_for<0, RBR>([&](auto T) MMG_INL {
+            constexpr int t = decltype(T)::value;
+            const int i = t * 16 + r;
+            if (my_op >= 0 && i < n) {
+                const int pc = rowcol[i];
+                if (pc >= 0 && pc < ss) xs[lc * ss + pc] = v[t][RBC] * srinv[i];
+            }
+        });
+        __syncthreads();
+        for (int idx = tid; idx < a.n_ops * ss; idx += 128) {
+            const int o = idx / ss, c = idx - o * ss;
+            const int op = a.ops[o];
+            const double div = op == RBF_OP_LAPLACE ? scale * scale : (op == RBF_OP_INTERP ? 1.0 : scale);
+            a.w[((size_t)o * a.n_eval + e) * ss + c] = xs[idx] / div;
+        }
+        __syncthreads();
+    }
+}
 #undef MMG_INL
 
 }  // namespace
@@ -715,6 +940,26 @@ static hipError_t launch_wave(const RbfArgs &a, int cus, hipStream_t s)
     return hipGetLastError();
 }
 
+static size_t rbf_wave2_lds_bytes(const RbfArgs &a)
+{
+    const size_t ss = (size_t)a.ss, n = (size_t)a.ss + a.pt, d1 = (size_t)a.poly_deg + 1;
+    const size_t bytes = (3 * ss + 3 * ss * d1 + n + (size_t)a.n_ops * ss + 8 * 10 + 2) * 8 + (4 + n) * 4 + 3 * (size_t)a.pt;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+static hipError_t launch_wave2(const RbfArgs &a, int cus, hipStream_t s)
+{
+    const size_t lds = rbf_wave2_lds_bytes(a);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rbf_weights_wave2_kernel<5, 9>, 128, lds) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    if (std::getenv("MMG_VERBOSE"))
+        std::fprintf(stderr, "[setup]   rbf_weights_wave2_kernel<5, 9>: %zu B of LDS, %d workgroups of two wavefronts per CU\n", lds, per_cu);
+    const long long blocks = std::min<long long>(a.n_eval, 4LL * cus * per_cu);
+    hipLaunchKernelGGL((rbf_weights_wave2_kernel<5, 9>), dim3((unsigned)blocks), dim3(128), lds, s, a);
+    return hipGetLastError();
+}
+
 // 0: no register kernel for this shape; else its RB
 static int rbf_wave_rb(int ss, int pt, int n_ops, double rbf_exp)
 {
@@ -740,7 +985,13 @@ hipError_t launch_rbf_weights(RbfArgs a, int cus, int lds_cu, hipStream_t s)
     switch (rbf_wave_rb(a.ss, a.pt, a.n_ops, a.rbf_exp)) {
     case 5: return launch_wave<5>(a, cus, s);
     case 7: return launch_wave<7>(a, cus, s);
-    case 9: return launch_wave<9>(a, cus, s);
+    case 9: {
+        static const bool env_one = []() {
+            const char *e = std::getenv("MMG_RBF_KERNEL");  // "one": one wavefront per stencil for every shape (A/B)
+            return e && e[0] == 'o';
+        }();
+        return (g_rbf_one_wave || env_one) ? launch_wave<9>(a, cus, s) : launch_wave2(a, cus, s);
+    }
     default: break;
     }
     if (a.ss + a.pt > 256) return hipErrorInvalidValue;

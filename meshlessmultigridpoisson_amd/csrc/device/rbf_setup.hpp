@@ -20,6 +20,7 @@ struct RbfArgs {
     double rbf_exp;
 };
 
+extern int g_rbf_one_wave;   // option "rbf_kernel" 2: systems of 57..72 unknowns in one wavefront instead of two
 extern int g_rbf_lds_only;  // option "rbf_kernel": 0 = automatic (register kernel where it applies), 1 = LDS kernel only
 
 // dynamic LDS of one workgroup of the LDS kernel; *ld_out = leading dimension of the column-major system

@@ -405,6 +405,12 @@ def test_rbf_register_kernel_matches_lds_kernel_and_reproduces_polynomials(host,
     assert np.isfinite(w).all()
     scale = np.abs(w_lds).max(axis=2, keepdims=True)
     assert (np.abs(w - w_lds) / scale).max() <= 1e-6
+    try:   # systems of 57..72 unknowns: two wavefronts per stencil by default, one with option 2 (same pivots)
+        _capi.set_option("rbf_kernel", 2)
+        w_one = _capi.rbf_weights(dim, deg, 3.0, xyz, ev, nbr, ops)
+    finally:
+        _capi.set_option("rbf_kernel", 0)
+    assert (np.abs(w_one - w_lds) / scale).max() <= 1e-6
     # polynomial reproduction in coordinates centred on the evaluation point (so the check does not cancel)
     rel = xyz[nbr] - ev[:, None, :]                                   # [n_eval][ss][3]
     h = np.abs(rel).max(axis=(1, 2))                                   # stencil radius
@@ -436,10 +442,21 @@ def test_rbf_register_kernel_on_coincident_stencil_points(host):
     xyz[1] = xyz[0]
     ev = xyz[:50].copy()
     nbr = np.tile(np.arange(25, dtype=np.int32), (50, 1))              # every stencil holds the coincident pair
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         try:
             _capi.set_option("rbf_kernel", mode)
             w = _capi.rbf_weights(2, 3, 3.0, xyz, ev, nbr, [0, 4])
+        finally:
+            _capi.set_option("rbf_kernel", 0)
+        assert np.isfinite(w).all()
+    # the same in 3-D: 70 x 70, the shape two wavefronts share (both must leave the elimination at the same step)
+    xyz3 = rng.random((400, 3))
+    xyz3[1] = xyz3[0]
+    nbr3 = np.tile(np.arange(50, dtype=np.int32), (50, 1))
+    for mode in (0, 1, 2):
+        try:
+            _capi.set_option("rbf_kernel", mode)
+            w = _capi.rbf_weights(3, 3, 3.0, xyz3, xyz3[:50].copy(), nbr3, [0, 1, 2, 3])
         finally:
             _capi.set_option("rbf_kernel", 0)
         assert np.isfinite(w).all()

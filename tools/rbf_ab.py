@@ -53,12 +53,12 @@ def main():
     n_eval = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     base = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rbf_ab")  # weights of both sides: too large for gpurun_out
     outs = {}
-    for side in ("wave", "lds"):
+    for side in ("wave", "one", "lds"):
         out = os.path.join(base, side)
         os.makedirs(out, exist_ok=True)
         env = dict(os.environ, MMG_VERBOSE="1")
-        if side == "lds":
-            env["MMG_RBF_KERNEL"] = "lds"
+        if side != "wave":
+            env["MMG_RBF_KERNEL"] = side   # "one": 57..72 unknowns in one wavefront instead of two; "lds": LDS kernel
         p = subprocess.run([sys.executable, __file__, "--child", str(n_eval), out], env=env, capture_output=True, text=True)
         log = [ln for ln in p.stderr.splitlines() if "rbf_weights" in ln]
         open(os.path.join(base, side + ".log"), "w").write(p.stderr)
@@ -73,7 +73,7 @@ def main():
         scale = np.abs(b).max(axis=2, keepdims=True)
         err = (np.abs(a - b) / scale).max()
         print(f"{key}: max |wave - lds| / row max = {err:.3e}  finite {np.isfinite(a).all()}")
-    for side in ("wave", "lds"):
+    for side in ("wave", "one", "lds"):
         print("--", side)
         for ln in outs[side][1]:
             if "stencils of" in ln and " 64 stencils" not in ln:
