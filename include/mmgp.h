@@ -141,9 +141,10 @@ int mmg_get_counter(const char *name, long long *value);
  * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on a quiet host (the
  * asynchronous launches never starve the stream), hence off by default; on a busy host the ~500 launches of a cycle
  * with 60 coarse-grid sweeps did starve it (bench.py turns the graph on for its V-cycle and fractional-step legs).
- * "rbf_kernel" (0 automatic / 1): mmg_rbf_weights / mmg_rbf_stencils -- 0: saddle systems of at most 72 x 72 with
- * rbf_exp 3 are factorised in the registers of one wavefront, the others in LDS; 1: the LDS kernel for every shape
- * (tests compare the two; different pivot ties, same solution to the conditioning of the system). */
+ * "rbf_kernel" (0 automatic / 1 / 2): mmg_rbf_weights / mmg_rbf_stencils -- 0: saddle systems of at most 72 x 72 with
+ * rbf_exp 3 are factorised in registers (one wavefront per stencil up to 56 unknowns, two above), the others in LDS;
+ * 1: the LDS kernel for every shape; 2: like 0 with one wavefront per stencil throughout (tests compare the three;
+ * different pivot ties than the LDS kernel, same solution to the conditioning of the system). */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
 int mmg_device_props(int *compute_units, int *lds_bytes_per_cu);
