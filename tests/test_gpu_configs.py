@@ -514,3 +514,74 @@ def test_config4_rank_share_of_the_342_cubed_cloud(host):
     assert np.array_equal(xd[no:], x0[no:])                      # ghost points are never relaxed
     rd, ro = lv.residual(), o.residual()
     assert np.abs(rd[:no] - ro[:no]).max() <= 1e-11 * np.abs(ro[:no]).max()
+
+
+@pytest.mark.gpu
+def test_config3_full_size_1e7_points(host):
+    """BASELINE configs[2] at its FULL size: 216^3 = 10 077 696 points, the reference's RBF-FD Laplacian (degree 3,
+    K = 50, device-batched setup), the level `bench.py` times.  (a) Directly against the CPU oracle: two SOR sweeps
+    (grid.cpp:104-146) 1e-12 relative, residual (grid.cpp:147-151) 1e-11; (b) the fused dependency-driven launch and
+    per-phase launches agree BIT FOR BIT (same arithmetic, same order); (c) size-independent properties: boundary
+    points are never relaxed; with b := A x* the exact solution is a fixed point of the sweep (1e-11: the rounding of
+    one row sum, amplified by omega / a_ii); the residual is linear in (x, b)."""
+    from meshlessmultigridpoisson_amd import _capi
+    pts = host.box_cloud(216, 3, seed=12345)
+    host.set_option("device_setup", 1)
+    try:
+        g = host.Grid.create_square(pts, 3, dim=3, kind=host.KIND_DIRICHLET, ordering=host.ORDER_MC, tile_points=0)
+    finally:
+        host.set_option("device_setup", -1)
+    sz = g.sizes()
+    n = sz["n"]
+    assert n == 216 ** 3
+    rng = np.random.default_rng(23)
+    x0 = rng.standard_normal(sz["a_size"])
+    b0 = rng.standard_normal(sz["a_size"])
+    g.set_values(x0)
+    g.set_source(b0)
+    lv = _capi.Level.borrow(g.device_level(), sz["n"], sz["a_size"])
+    info = lv.info()
+    assert info["sor_rows"] == 214 ** 3
+    la = g.level_arrays()
+    bnd = la["bcflags"] != 0
+    o = H.oracle_level(la)
+    # (a) + (b)
+    _capi.set_option("persistent_sweep", 0)
+    try:
+        lv.sweeps(2)
+        x_phase = lv.get_x()
+    finally:
+        _capi.set_option("persistent_sweep", 1)
+    lv.set_x(x0)
+    lv.sweeps(2)
+    xd = lv.get_x()
+    assert np.array_equal(xd, x_phase)
+    o.sor_sweeps(2)
+    assert np.abs(xd - o.x).max() <= 1e-12 * np.abs(o.x).max()
+    assert np.array_equal(xd[bnd], x0[bnd])
+    rd, ro = lv.residual(), o.residual()
+    assert np.abs(rd - ro).max() <= 1e-11 * np.abs(ro).max()
+    del o
+    # (c) linearity of the residual: r(x1 + x2, b1 + b2) = r(x1, b1) + r(x2, b2) on the relaxed rows
+    x1 = rng.standard_normal(sz["a_size"])
+    b1 = rng.standard_normal(sz["a_size"])
+    lv.set_x(x1)
+    lv.set_rhs(b1)
+    r1 = lv.residual()
+    lv.set_x(x0 + x1)
+    lv.set_rhs(b0 + b1)
+    r01 = lv.residual()
+    lv.set_x(x0)
+    lv.set_rhs(b0)
+    r0 = lv.residual()
+    scale = np.abs(r0).max() + np.abs(r1).max()
+    assert np.abs(r01 - (r0 + r1))[~bnd].max() <= 1e-12 * scale
+    # fixed point: b := A x* (= -r(x*, 0)) makes x* the solution; sweeps leave it where it is
+    lv.set_x(x1)
+    lv.set_rhs(np.zeros(sz["a_size"]))
+    ax = -lv.residual()
+    ax[bnd] = 0.0
+    lv.set_rhs(ax)
+    lv.sweeps(3)
+    xs = lv.get_x()
+    assert np.abs(xs - x1).max() <= 1e-11 * np.abs(x1).max()
