@@ -554,7 +554,6 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
                 }
                 v[ai][bi] = val;
                 m = fmax(m, fabs(val));
-                __builtin_amdgcn_sched_barrier(0);  // one element at a time: the block must not share its registers with 81 half-finished elements
             });
             v[ai][RB] = (my_op >= 0 && i < n) ? rhs_entry<true>(my_op, i, ss, a.dim, 3.0, xi, yi, zi, ea_i, eb_i, ec_i, xe, ye, ze) : 0.0;
             if (((ract >> ai) & 1u) && m > best) { best = m; bidx = ai; }
@@ -775,7 +774,6 @@ __global__ __launch_bounds__(128, 2) void rbf_weights_wave2_kernel(RbfArgs a)
                 }
                 v[ai][bi] = val;
                 m = fmax(m, fabs(val));
-                __builtin_amdgcn_sched_barrier(0);
             });
             v[ai][RBC] = (my_op >= 0 && i < n) ? rhs_entry<true>(my_op, i, ss, a.dim, 3.0, xi, yi, zi, ea_i, eb_i, ec_i, xe, ye, ze) : 0.0;
             if (((ract >> ai) & 1u) && m > best) { best = m; bidx = ai; }
