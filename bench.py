@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--replicate-below", type=int, default=70000,
                     help="N>1 V-cycle leg: levels with fewer points are kept complete on every rank")
     ap.add_argument("--no-fracstep", action="store_true", help="skip the 3-D fractional-step leg (N=1)")
+    ap.add_argument("--dd-legs-timeout", type=float, default=300.0,
+                    help="N>1: seconds the optional distributed legs (V-cycle, fractional step) may take together; after that "
+                         "rank 0 prints the line with the sweep figures already measured and every rank leaves")
     ap.add_argument("--vcycle-cycles", type=int, default=10)
     ap.add_argument("--verify", type=int, default=0,
                     help="N: run N sweeps in per-phase mode and in --persistent mode from the same state; must agree bitwise")
@@ -641,18 +644,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 vcycles.insert(li, {"workload": "BASELINE configs[1]: " + what, "error": str(e)})
 
-    if dd and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:
-        try:
-            multi["vcycle"] = distributed_vcycle_leg(a, rank, world, dist)
-        except Exception as e:  # noqa: BLE001 -- the sweep figures do not depend on this leg
-            multi["vcycle"] = {"error": str(e)}
-    if dd and not a.no_fracstep and a.operator == "rbf" and a.dim == 3:
-        try:
-            multi["fracstep"] = distributed_fracstep_leg(a, rank, world, dist)
-        except Exception as e:  # noqa: BLE001
-            multi["fracstep"] = {"error": str(e)}
-
-    if rank == 0:
+    def build_out():
         if strong:
             wl = (f"{a.dim}-D {a.total_nside}^{a.dim} = {a.total_nside ** a.dim} points in ONE cloud shared by {world} "
                   f"GPUs ({'x-slabs' if a.partition == 'slab' else 'boxes'}; BASELINE configs[3] at 8 GPUs)")
@@ -708,6 +700,55 @@ def main():
             out["multi_gpu"] = multi
         if vcycles:
             out["vcycle"] = vcycles
+        return out
+
+    # The distributed legs below are optional and full of collectives: should one of them never return (a rank that
+    # left a collective the others wait in), the sweep figures above are already measured -- a watchdog lets rank 0
+    # print the line without the leg and every rank leave, instead of the whole bench running into the driver's limit.
+    import threading
+    out_lock = threading.Lock()
+    wd = None
+    if dd:
+        legs_wanted = [k for k, w in (("vcycle", not a.no_vcycle), ("fracstep", not a.no_fracstep))
+                       if w and a.operator == "rbf" and a.dim == 3]
+
+        def _legs_expired():
+            out_lock.acquire()          # never released: the process ends here
+            if rank == 0:
+                for k in legs_wanted:
+                    if k not in multi:
+                        multi[k] = {"error": f"no result within {a.dd_legs_timeout:g} s (bench.py watchdog)"}
+                multi["legs_watchdog_fired"] = True
+                o = build_out()
+                sys.stdout.flush()
+                os.dup2(real_stdout, 1)
+                print(json.dumps(o), flush=True)
+            else:
+                time.sleep(2.0)         # rank 0 prints first
+            os._exit(0)
+
+        if legs_wanted and a.dd_legs_timeout > 0:
+            wd = threading.Timer(a.dd_legs_timeout, _legs_expired)
+            wd.daemon = True
+            wd.start()
+    if dd and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:
+        try:
+            multi["vcycle"] = distributed_vcycle_leg(a, rank, world, dist)
+        except Exception as e:  # noqa: BLE001 -- the sweep figures do not depend on this leg
+            multi["vcycle"] = {"error": str(e)}
+    if dd and not a.no_fracstep and a.operator == "rbf" and a.dim == 3:
+        try:
+            multi["fracstep"] = distributed_fracstep_leg(a, rank, world, dist)
+        except Exception as e:  # noqa: BLE001
+            multi["fracstep"] = {"error": str(e)}
+
+    if wd is not None:
+        out_lock.acquire()              # if the watchdog holds it, it is printing: the process ends there
+        wd.cancel()
+        out_lock.release()
+
+    if rank == 0:
+        out = build_out()
         if not dd and not a.no_fracstep and not a.no_vcycle and a.operator == "rbf" and a.dim == 3:
             try:
                 out["fracstep"] = fracstep_leg()
