@@ -141,9 +141,9 @@ int mmg_get_counter(const char *name, long long *value);
  * iters or the boundary data change.  Single-GPU hierarchies only.  Measured neutral on a quiet host (the
  * asynchronous launches never starve the stream), hence off by default; on a busy host the ~500 launches of a cycle
  * with 60 coarse-grid sweeps did starve it (bench.py turns the graph on for its V-cycle and fractional-step legs).
- * "rbf_kernel" (0 automatic / 1 / 2): mmg_rbf_weights / mmg_rbf_stencils -- 0: saddle systems of at most 72 x 72 with
+ * "rbf_kernel" (0 automatic / 1 / 2): mmg_rbf_weights / mmg_rbf_stencils -- 0: saddle systems of at most 104 x 104 with
  * rbf_exp 3 are factorised in registers (one wavefront per stencil up to 56 unknowns, two above), the others in LDS;
- * 1: the LDS kernel for every shape; 2: like 0 with one wavefront per stencil throughout (tests compare the three;
+ * 1: the LDS kernel for every shape; 2: like 0 with one wavefront per stencil up to 72 unknowns (tests compare the three;
  * different pivot ties than the LDS kernel, same solution to the conditioning of the system). */
 int mmg_set_option(const char *name, int value);
 /* compute units and LDS bytes per CU of the current device (256 / 163840 on MI355X) */
@@ -302,7 +302,7 @@ int mmg_spmv_apply(mmg_spmv *m, const double *x, int nx, double *y, int ny);
  *                           solved against ONE factorisation)
  *   weights   [n_ops][n_eval][stencil]  out: the first `stencil` solution entries
  * Full pivoting as fullPivLu, i.e. the same pivot VALUES; among equal candidates the register kernel (systems up
- * to 72 x 72) takes another one than Eigen's column-major scan, and it eliminates Gauss-Jordan fashion: weights
+ * to 104 x 104) takes another one than Eigen's column-major scan, and it eliminates Gauss-Jordan fashion: weights
  * agree with the reference's to the conditioning of the scaled saddle system (tests: 1e-6 of the row's largest). */
 int mmg_rbf_weights(int dim, int poly_deg, double rbf_exp, int stencil, int n_cloud, const double *cloud_xyz,
                     long long n_eval, const double *eval_xyz, const int *nbr, int n_ops, const int *ops,

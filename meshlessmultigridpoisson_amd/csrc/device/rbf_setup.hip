@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NT, 4) void rbf_weights_kernel(RbfArgs a)  // four 
 }
 
 
-// ---- one wavefront per stencil, the system in registers (systems of at most 72 x 72) --------------------
+// ---- one wavefront per stencil, the system in registers (systems of at most 72 x 72; larger ones: two wavefronts, below) ----
 // The 64 lanes form an 8 x 8 grid; lane (lr, lc) = (lane >> 3, lane & 7) keeps the RB x RB elements (a * 8 + lr,
 // b * 8 + lc) of the saddle system in registers, plus one more local column (b = RB): entry a * 8 + lr of the
 // right-hand side of operator lc.  Full pivoting WITHOUT moving data: a pivot (pr, pc) retires row pr and column pc
@@ -653,7 +653,8 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
     }
 }
 
-// ---- two wavefronts per stencil (57 <= n <= 72: the 70 x 70 systems of the 3-D degree-3 stencils) ----
+// ---- two wavefronts per stencil (57 <= n <= 72: the 70 x 70 systems of the 3-D degree-3 stencils; 73 <= n <= 104:
+// the 98 x 98 systems of the reference's live 2-D degree-6 stencils, with 7 x 14 values per lane) ----
 // The RB = 9 block of the kernel above fills the register file of a SIMD with ONE wavefront.  Here a workgroup of two
 // wavefronts shares the stencil: a 16 x 8 lane grid, wavefront w owns the lane rows 8w .. 8w + 7, lane (r, c) the
 // RBR x RBC elements (16a + r, 8b + c) and entry 16a + r of the right-hand side of operator c -- 5 x 10 instead of
@@ -661,8 +662,8 @@ __global__ __launch_bounds__(64, (RB <= 7 ? 2 : 1)) void rbf_weights_wave_kernel
 // all columns of its rows: ds_bpermute along the lane rows as above); the pivot ROW lives in one wavefront and
 // reaches the other through LDS, as does the choice between the two wavefronts' pivot candidates: two workgroup
 // barriers per step, nothing else crosses.
-template <int RBR, int RBC>
-__global__ __launch_bounds__(128, 2) void rbf_weights_wave2_kernel(RbfArgs a)
+template <int RBR, int RBC, int OCC>
+__global__ __launch_bounds__(128, OCC) void rbf_weights_wave2_kernel(RbfArgs a)
 {
     constexpr int CB = RBC + 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -938,23 +939,25 @@ static hipError_t launch_wave(const RbfArgs &a, int cus, hipStream_t s)
     return hipGetLastError();
 }
 
-static size_t rbf_wave2_lds_bytes(const RbfArgs &a)
+static size_t rbf_wave2_lds_bytes(const RbfArgs &a, int cb)
 {
     const size_t ss = (size_t)a.ss, n = (size_t)a.ss + a.pt, d1 = (size_t)a.poly_deg + 1;
-    const size_t bytes = (3 * ss + 3 * ss * d1 + n + (size_t)a.n_ops * ss + 8 * 10 + 2) * 8 + (4 + n) * 4 + 3 * (size_t)a.pt;
+    const size_t bytes = (3 * ss + 3 * ss * d1 + n + (size_t)a.n_ops * ss + 8 * (size_t)cb + 2) * 8 + (4 + n) * 4 + 3 * (size_t)a.pt;
     return (bytes + 15) & ~(size_t)15;
 }
 
+template <int RBR, int RBC, int OCC>
 static hipError_t launch_wave2(const RbfArgs &a, int cus, hipStream_t s)
 {
-    const size_t lds = rbf_wave2_lds_bytes(a);
+    const size_t lds = rbf_wave2_lds_bytes(a, RBC + 1);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rbf_weights_wave2_kernel<5, 9>, 128, lds) != hipSuccess || per_cu < 1)
-        per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rbf_weights_wave2_kernel<RBR, RBC, OCC>, 128, lds) != hipSuccess || per_cu < 1)
+        per_cu = 2;
     if (std::getenv("MMG_VERBOSE"))
-        std::fprintf(stderr, "[setup]   rbf_weights_wave2_kernel<5, 9>: %zu B of LDS, %d workgroups of two wavefronts per CU\n", lds, per_cu);
+        std::fprintf(stderr, "[setup]   rbf_weights_wave2_kernel<%d, %d>: %zu B of LDS, %d workgroups of two wavefronts per CU\n", RBR, RBC, lds,
+                     per_cu);
     const long long blocks = std::min<long long>(a.n_eval, 4LL * cus * per_cu);
-    hipLaunchKernelGGL((rbf_weights_wave2_kernel<5, 9>), dim3((unsigned)blocks), dim3(128), lds, s, a);
+    hipLaunchKernelGGL((rbf_weights_wave2_kernel<RBR, RBC, OCC>), dim3((unsigned)blocks), dim3(128), lds, s, a);
     return hipGetLastError();
 }
 
@@ -966,8 +969,8 @@ static int rbf_wave_rb(int ss, int pt, int n_ops, double rbf_exp)
         return (e && e[0] == 'l') ? 0 : 1;
     }();
     const int n = ss + pt;
-    if (!mode || g_rbf_lds_only || n_ops > 8 || n > 72 || rbf_exp != 3.0) return 0;  // the register kernel: r^3, the reference's rbfExp
-    return n <= 40 ? 5 : (n <= 56 ? 7 : 9);
+    if (!mode || g_rbf_lds_only || n_ops > 8 || n > 104 || ss > 128 || rbf_exp != 3.0) return 0;  // the register kernels: r^3, the reference's rbfExp
+    return n <= 40 ? 5 : (n <= 56 ? 7 : (n <= 72 ? 9 : 13));
 }
 
 bool rbf_supported(int ss, int pt, int n_ops, double rbf_exp, int lds_cu)
@@ -988,8 +991,9 @@ hipError_t launch_rbf_weights(RbfArgs a, int cus, int lds_cu, hipStream_t s)
             const char *e = std::getenv("MMG_RBF_KERNEL");  // "one": one wavefront per stencil for every shape (A/B)
             return e && e[0] == 'o';
         }();
-        return (g_rbf_one_wave || env_one) ? launch_wave<9>(a, cus, s) : launch_wave2(a, cus, s);
+        return (g_rbf_one_wave || env_one) ? launch_wave<9>(a, cus, s) : launch_wave2<5, 9, 2>(a, cus, s);
     }
+    case 13: return launch_wave2<7, 13, 1>(a, cus, s);  // 73..104 unknowns (2-D degree 6: 98): 7 x 14 values per lane, one wavefront per SIMD
     default: break;
     }
     if (a.ss + a.pt > 256) return hipErrorInvalidValue;

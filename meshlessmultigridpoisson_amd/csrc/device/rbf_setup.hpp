@@ -25,7 +25,7 @@ extern int g_rbf_lds_only;  // option "rbf_kernel": 0 = automatic (register kern
 
 // dynamic LDS of one workgroup of the LDS kernel; *ld_out = leading dimension of the column-major system
 size_t rbf_lds_bytes(int ss, int pt, int n_ops, int *ld_out);
-// a kernel exists for this shape on a device with lds_cu bytes of LDS per CU: systems of at most 72 x 72 with the
+// a kernel exists for this shape on a device with lds_cu bytes of LDS per CU: systems of at most 104 x 104 with the
 // cubic PHS (rbf_exp 3) are factorised in the registers of one wavefront, the others (up to 256 x 256) in LDS
 bool rbf_supported(int ss, int pt, int n_ops, double rbf_exp, int lds_cu);
 // picks the kernel, its grid and its LDS (a.ld is set here)

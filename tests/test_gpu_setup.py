@@ -385,7 +385,8 @@ def test_rbf_register_kernel_matches_lds_kernel_and_reproduces_polynomials(host,
     "rbf_kernel"): weights equal to 1e-6 of the row's largest (conditioning of the scaled saddle systems; observed
     2e-7), and -- independent of either -- every row reproduces the operator on all monomials up to polyDeg, which
     is what the polynomial block of the saddle system enforces (1e-8 relative to the row's magnitude).  (2, 5, 51) is
-    the largest system of the register kernel (72 x 72), (2, 6, 70) is 98 x 98: LDS kernel on both sides."""
+    the largest system two wavefronts share at two per SIMD (72 x 72), (2, 6, 70) is 98 x 98 -- the reference's live
+    fine polyDeg 6 (FractionalStepSim.cpp:201-203): two wavefronts with 7 x 14 values per lane."""
     from meshlessmultigridpoisson_amd import _capi
     rng = np.random.default_rng(11)
     side = 40 if dim == 2 else 14
