@@ -970,7 +970,7 @@ static int rbf_wave_rb(int ss, int pt, int n_ops, double rbf_exp)
     }();
     const int n = ss + pt;
     if (!mode || g_rbf_lds_only || n_ops > 8 || n > 104 || ss > 128 || rbf_exp != 3.0) return 0;  // the register kernels: r^3, the reference's rbfExp
-    return n <= 40 ? 5 : (n <= 56 ? 7 : (n <= 72 ? 9 : 13));
+    return n <= 40 ? 5 : (n <= 56 ? 7 : (n <= 72 ? 9 : (n <= 80 ? 10 : 13)));
 }
 
 bool rbf_supported(int ss, int pt, int n_ops, double rbf_exp, int lds_cu)
@@ -993,6 +993,7 @@ hipError_t launch_rbf_weights(RbfArgs a, int cus, int lds_cu, hipStream_t s)
         }();
         return (g_rbf_one_wave || env_one) ? launch_wave<9>(a, cus, s) : launch_wave2<5, 9, 2>(a, cus, s);
     }
+    case 10: return launch_wave2<5, 10, 2>(a, cus, s);  // 73..80 unknowns (2-D degree 5: 52 + 21 = 73)
     case 13: return launch_wave2<7, 13, 1>(a, cus, s);  // 73..104 unknowns (2-D degree 6: 98): 7 x 14 values per lane, one wavefront per SIMD
     default: break;
     }

@@ -377,14 +377,15 @@ def test_fracstep_operator_cache_follows_polydeg_changes(host):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dim,deg,ss,ops", [(3, 3, 50, [0]), (3, 3, 50, [1, 2, 3, 0]), (2, 3, 25, [0, 1, 2]), (2, 4, 37, [4]),
-                                            (2, 5, 51, [0]), (3, 2, 30, [0, 4]), (2, 6, 70, [0])])
+                                            (2, 5, 51, [0]), (2, 5, 52, [0, 1]), (3, 2, 30, [0, 4]), (2, 6, 70, [0])])
 def test_rbf_register_kernel_matches_lds_kernel_and_reproduces_polynomials(host, dim, deg, ss, ops):
     """The two kernels behind mmg_rbf_weights (rbf_setup.hip): systems of at most 72 x 72 are factorised in the
     registers of one wavefront (Gauss-Jordan, full pivoting without data movement), larger ones in LDS (LU with full
     pivoting as the reference's fullPivLu, grid.cpp:304-424, :687-712).  Same stencils through both (option
     "rbf_kernel"): weights equal to 1e-6 of the row's largest (conditioning of the scaled saddle systems; observed
     2e-7), and -- independent of either -- every row reproduces the operator on all monomials up to polyDeg, which
-    is what the polynomial block of the saddle system enforces (1e-8 relative to the row's magnitude).  (2, 5, 51) is
+    is what the polynomial block of the saddle system enforces (1e-8 relative to the row's magnitude).  (2, 5, 52) is the
+    reference's degree-5 stencil (73 x 73: two wavefronts, 5 x 11 values per lane), (2, 5, 51) is
     the largest system two wavefronts share at two per SIMD (72 x 72), (2, 6, 70) is 98 x 98 -- the reference's live
     fine polyDeg 6 (FractionalStepSim.cpp:201-203): two wavefronts with 7 x 14 values per lane."""
     from meshlessmultigridpoisson_amd import _capi

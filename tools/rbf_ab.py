@@ -22,6 +22,7 @@ SHAPES = [  # dim, polyDeg, stencil, ops
     (2, 3, 25, [0, 1, 2]),
     (2, 4, 37, [0]),
     (2, 5, 51, [0]),
+    (2, 5, 52, [0]),
     (3, 2, 30, [0, 4]),
     (2, 6, 70, [0, 1, 2]),
 ]
