@@ -1744,12 +1744,12 @@ int mmg_transfer_create(mmg_transfer **out, int rows, int cols, const int *outer
     std::vector<int32_t> rows_all((size_t)rows);
     for (int i = 0; i < rows; ++i) rows_all[i] = i;
     CsrView A{rows, cols, t->rowptr.data(), t->col.data(), t->val.data()};
-    // lanes per row as for the levels (mmg_level_create): long rows (3-D K = 50) stream best with 2 lanes, shorter ones
-    // keep 4 -- 216^3 4-level cycle 17.23 -> 16.93 ms on one box (8 lanes: 17.41; tiles of 128 / 512 rows instead of
-    // 256: no difference).  MMG_TRANSFER_LANES overrides (A/B).
+    // 2 lanes per row (32 rows per group; rows of fewer than 20 entries keep 4): 216^3 4-level cycle 17.23 -> 16.93 ms
+    // (8 lanes: 17.41; tiles of 128 / 512 rows instead of 256: no difference), 2-D 1e6-point 7-level cycle (K = 25 / 37)
+    // 5.21 -> 5.14 ms (8 lanes: 5.31, 16: 5.65), same box each.  MMG_TRANSFER_LANES overrides (A/B).
     static const int t_forced = []() { const char *e = std::getenv("MMG_TRANSFER_LANES"); const int v = e ? std::atoi(e) : 0; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 0; }();
     const double avg_row = (double)t->rowptr[(size_t)rows] / (double)rows;
-    const int t_lanes = t_forced ? t_forced : (avg_row >= 44.0 ? 2 : 4);
+    const int t_lanes = t_forced ? t_forced : (avg_row >= 20.0 ? 2 : 4);
     const int t_tile = 256;
     if ((rc = build_gather_plan(A, rows_all, t_lanes, t_tile, false, false, false, -1, &t->all))) return rc;
     *out = t.release();
